@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# Build the reference's own CPU checkers into oracle/_ref/ (TEST INFRASTRUCTURE).
+# Compiles the sources where they lie under the read-only reference tree; nothing
+# is copied.  No-op (exit 0) when the reference tree is absent (GPU box).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+ref="${GRX_REFERENCE_ROOT:-/root/reference}"
+out="$here/_ref"
+if [ ! -d "$ref/examples/algorithms/bfs" ]; then
+  echo "ref_build: $ref not present; keeping prebuilt $out (if any)"; exit 0
+fi
+mkdir -p "$out"
+hipcc -x hip --cuda-host-only -std=c++17 -O3 -fPIC -shared \
+  -DGRX_REF_BFS_CPU="\"$ref/examples/algorithms/bfs/bfs_cpu.hxx\"" \
+  -DGRX_REF_SSSP_CPU="\"$ref/examples/algorithms/sssp/sssp_cpu.hxx\"" \
+  "$here/ref_driver.cpp" -o "$out/libgrx_ref_oracle.so"
+echo "ref_build: built $out/libgrx_ref_oracle.so"
