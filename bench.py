@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- traversed edges/sec (MTEPS), BFS + SSSP on synthetic R-MAT, N x MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scale 22] [--lb block_mapped]
+
+One *step* = one BFS followed by one SSSP from the same source (source 0 first, then seeded
+random non-isolated vertices) through the HIP path (`libessentials_amd.so`).  The graph is
+generated on the GPU and is resident in HBM before the timed region; labels stay on the device.
+`value` = (sum over steps of the out-degrees of the vertices each traversal reached, BFS and
+SSSP both) / wall time of the K steps (barrier + synchronize on both sides, max over ranks).
+Prints ONE JSON line (rank 0).  For N > 1 launch with
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
+
+Extra objects on the line (prompt section 4):
+  roofline     dominant kernel = the BFS advance kernels; achieved = algorithmic bytes of one BFS
+               (8 B per traversed edge + 20 B per reached vertex) / summed advance
+               kernel time of that BFS measured with HIP events on the engine's stream.
+  cpu_baseline the reference's own CPU checker (oracle/_ref, kind "reference") or its C
+               restatement (oracle/, kind "port") timed on this box's host, 1 core, one BFS + one
+               SSSP from source 0 on the same graph.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--lb", default="block_mapped")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--weight-seed", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", default="bfs+sssp", choices=["bfs+sssp", "bfs", "sssp"])
+    return ap.parse_args()
+
+
+def pick_sources(deg, steps, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    cand = np.flatnonzero(deg > 0)
+    extra = rng.choice(cand, size=max(steps - 1, 0), replace=len(cand) < steps)
+    return [0] + [int(x) for x in extra]
+
+
+def cpu_baseline(Ap, Aj, Ax, algo):
+    """Reference CPU path on the host cores of this box (1 thread, like the reference)."""
+    from oracle.oracle import Oracle, RefOracle, build
+    build()
+    kind = "reference" if RefOracle.available() else "port"
+    import numpy as np
+    deg = np.diff(Ap).astype(np.int64)
+    edges = 0
+    ms = 0.0
+    t0 = time.time()
+    if RefOracle.available():
+        r = RefOracle()
+        if "bfs" in algo:
+            d, t = r.bfs(Ap, Aj, 0); ms += t; edges += int(deg[d != 2**31 - 1].sum())
+        if "sssp" in algo:
+            w, t = r.sssp(Ap, Aj, Ax, 0); ms += t; edges += int(deg[w < 3e38].sum())
+    else:
+        o = Oracle()
+        if "bfs" in algo:
+            d, t = o.bfs_heap(Ap, Aj, 0); ms += t; edges += int(deg[d != 2**31 - 1].sum())
+        if "sssp" in algo:
+            w, t = o.sssp_heap(Ap, Aj, Ax, 0); ms += t; edges += int(deg[w < 3e38].sum())
+    return {"value": edges / (ms * 1e-3) / 1e6, "unit": "MTEPS", "cores": 1, "kind": kind,
+            "sample": f"one {algo} from source 0 on the same R-MAT graph, search loops only "
+                      f"({ms:.0f} ms of {time.time() - t0:.0f} s wall)"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import essentials_amd as ea
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    ctx = ea.Context(local_rank)
+    lb = ea.LoadBalance[a.lb]
+    opts = ea.Options(load_balance=lb)
+
+    if world > 1:
+        from essentials_amd.distributed import PartitionedRunner
+        runner = PartitionedRunner(ctx, dist, a.scale, a.edge_factor, a.seed, a.weight_seed)
+    else:
+        from essentials_amd.distributed import SingleRunner
+        runner = SingleRunner(ctx, a.scale, a.edge_factor, a.seed, a.weight_seed)
+
+    deg = runner.global_degrees()            # numpy int64 [V] (same on every rank)
+    sources = pick_sources(deg, a.steps + a.warmup, a.seed + 99)
+
+    def step(src):
+        e = 0
+        if "bfs" in a.algo:
+            e += runner.bfs(src, opts)
+        if "sssp" in a.algo:
+            e += runner.sssp(src, opts)
+        return e
+
+    def fence():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(sources[i])
+    fence()
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(a.steps):
+        edges += step(sources[a.warmup + i])
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (BFS advance), outside the timed region ----
+    roof = runner.bfs_roofline(sources[a.warmup], lb)
+    out = {
+        "metric": "traversed edges/sec (MTEPS) BFS+SSSP on RMAT-%d" % a.scale,
+        "value": edges / dt / 1e6,
+        "unit": "MTEPS",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int32 ids / f32 weights",
+        "data": "synthetic",
+        "config": {"workload": f"BFS+SSSP on RMAT scale-{a.scale} edgefactor-{a.edge_factor} "
+                               f"(symmetrized, {runner.nnz} directed edges), {a.lb} advance, "
+                               f"{world}xMI355X",
+                   "algo": a.algo, "load_balance": a.lb, "vertices": runner.n, "edges": runner.nnz,
+                   "partitioning": "none" if world == 1 else f"1-D vertex ranges x{world}, RCCL all-gather"},
+        "roofline": roof,
+        "detail": runner.detail(),
+    }
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            Ap, Aj, Ax = runner.host_csr()
+            out["cpu_baseline"] = cpu_baseline(Ap, Aj, Ax, a.algo)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,415 @@
+"""ctypes binding of include/essentials_amd.h and a small object layer over it.
+
+Names follow the reference's domain (graph, frontier, advance, filter, enactor stats).
+Mirrors, argument for argument, ``gunrock::{bfs,sssp,pr}::run`` (reference
+algorithms/bfs.hxx:151-176, sssp.hxx:155-185, pr.hxx:182-216) and the frontier-level
+operator overloads (advance.hxx:91-129, filter.hxx:59-86, uniquify.hxx:15-42).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libessentials_amd.so")
+
+INT_UNREACHED = 2**31 - 1
+FLT_UNREACHED = float(np.finfo(np.float32).max)
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call failed (the C++ surface threw gunrock::error::exception_t)."""
+
+
+class LoadBalance(enum.IntEnum):
+    thread_mapped = 0
+    warp_mapped = 1
+    block_mapped = 2
+    bucketing = 3
+    merge_path = 4
+    merge_path_v2 = 5
+    work_stealing = 6
+
+
+class FilterAlgorithm(enum.IntEnum):
+    remove = 0
+    predicated = 1
+    compact = 2
+    bypass = 3
+
+
+class UniquifyAlgorithm(enum.IntEnum):
+    unique = 0
+    unique_copy = 1
+
+
+class EdgeOp(enum.IntEnum):
+    all = 0
+    bfs = 1
+    sssp = 2
+    count_edge = 3
+    sum_weight = 4
+
+
+class VertexOp(enum.IntEnum):
+    all = 0
+    odd = 1
+    once = 2
+    count = 3
+
+
+class _Options(C.Structure):
+    _fields_ = [("load_balance", C.c_int32), ("holes_layout", C.c_int32),
+                ("hub_threshold", C.c_int32), ("max_iterations", C.c_int32),
+                ("frontier_sizing_factor", C.c_float), ("collect_kernel_time", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("elapsed_ms", C.c_float), ("advance_kernel_ms", C.c_float),
+                ("iterations", C.c_int32), ("advance_launches", C.c_int32),
+                ("vertices_reached", C.c_int64), ("edges_traversed", C.c_int64),
+                ("levels_recorded", C.c_int32), ("reserved", C.c_int32),
+                ("frontier_slots", C.c_int64 * 64)]
+
+
+@dataclass
+class Options:
+    load_balance: LoadBalance = LoadBalance.block_mapped
+    holes_layout: bool = False
+    hub_threshold: int = 0
+    max_iterations: int = 0
+    frontier_sizing_factor: float = 1.5
+    collect_kernel_time: bool = False
+
+    def _c(self) -> _Options:
+        o = _Options()
+        o.load_balance = int(self.load_balance)
+        o.holes_layout = int(self.holes_layout)
+        o.hub_threshold = int(self.hub_threshold)
+        o.max_iterations = int(self.max_iterations)
+        o.frontier_sizing_factor = float(self.frontier_sizing_factor)
+        o.collect_kernel_time = int(self.collect_kernel_time)
+        return o
+
+
+@dataclass
+class Stats:
+    elapsed_ms: float = 0.0
+    advance_kernel_ms: float = 0.0
+    iterations: int = 0
+    advance_launches: int = 0
+    vertices_reached: int = 0
+    edges_traversed: int = 0
+    frontier_slots: list = field(default_factory=list)
+
+    @staticmethod
+    def _from(s: _Stats) -> "Stats":
+        return Stats(s.elapsed_ms, s.advance_kernel_ms, s.iterations, s.advance_launches,
+                     s.vertices_reached, s.edges_traversed,
+                     list(s.frontier_slots[: s.levels_recorded]))
+
+
+# symbol -> (restype, argtypes); the list is also what tests check against the header
+_VP = C.c_void_p
+_SIGNATURES = {
+    "grx_abi_version": (C.c_int, []),
+    "grx_last_error": (C.c_char_p, []),
+    "grx_default_options": (None, [C.POINTER(_Options)]),
+    "grx_context_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    "grx_context_destroy": (C.c_int, [_VP]),
+    "grx_context_synchronize": (C.c_int, [_VP]),
+    "grx_context_device_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]),
+    "grx_graph_from_device_csr": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP,
+                                            C.POINTER(_VP)]),
+    "grx_graph_from_host_csr": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP,
+                                          C.POINTER(_VP)]),
+    "grx_graph_from_mtx": (C.c_int, [C.c_char_p, C.POINTER(_VP)]),
+    "grx_graph_from_csr_file": (C.c_int, [C.c_char_p, C.POINTER(_VP)]),
+    "grx_graph_write_csr_file": (C.c_int, [_VP, C.c_char_p]),
+    "grx_graph_rmat": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                 C.POINTER(_VP)]),
+    "grx_graph_destroy": (C.c_int, [_VP]),
+    "grx_graph_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int64), C.POINTER(_VP), C.POINTER(_VP),
+                                 C.POINTER(_VP)]),
+    "grx_graph_copy_to_host": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "grx_bfs": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, C.POINTER(_Options), C.POINTER(_Stats)]),
+    "grx_sssp": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, C.POINTER(_Options), C.POINTER(_Stats)]),
+    "grx_pagerank": (C.c_int, [_VP, _VP, C.c_float, C.c_float, _VP, C.POINTER(_Options),
+                               C.POINTER(_Stats)]),
+    "grx_advance": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, C.c_int32, _VP,
+                              C.c_int64, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "grx_filter": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int32, _VP, C.c_int64, _VP,
+                             C.c_int64, C.POINTER(C.c_int64)]),
+    "grx_uniquify": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP, C.c_int64,
+                               C.POINTER(C.c_int64)]),
+    "grx_comm_unique_id": (C.c_int, [_VP]),
+    "grx_comm_attach": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "grx_comm_detach": (C.c_int, [_VP]),
+    "grx_graph_rmat_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                           C.c_int, C.POINTER(_VP), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int32)]),
+    "grx_graph_partition": (C.c_int, [_VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32)]),
+    "grx_bfs_partitioned": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP,
+                                      C.POINTER(_Options), C.POINTER(_Stats)]),
+    "grx_sssp_partitioned": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP,
+                                       C.POINTER(_Options), C.POINTER(_Stats)]),
+    "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libessentials_amd.so; there is no fallback of any kind."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise EngineError(
+            f"{_LIB_PATH} is missing: build it with `python -m essentials_amd.build` "
+            "(hipcc --offload-arch=gfx950). essentials_amd has no CPU path.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.grx_abi_version() != 1:
+        raise EngineError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().grx_last_error()
+        raise EngineError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def _ptr(t) -> Optional[int]:
+    """Device (torch) or host (numpy) pointer of an array-like, None -> NULL."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+class Context:
+    """gcuda::multi_context_t(device[, stream])  (reference cuda/context.hxx:136-206)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._h = _VP()
+        _check(load_library().grx_context_create(device, stream, C.byref(self._h)),
+               "grx_context_create")
+        self.device = device
+
+    def synchronize(self) -> None:
+        _check(load_library().grx_context_synchronize(self._h), "grx_context_synchronize")
+
+    def device_info(self) -> dict:
+        cus, wave, mem = C.c_int32(), C.c_int32(), C.c_int64()
+        name = C.create_string_buffer(256)
+        _check(load_library().grx_context_device_info(self._h, cus, wave, mem, name, 256),
+               "grx_context_device_info")
+        return {"name": name.value.decode(), "compute_units": cus.value,
+                "wavefront_size": wave.value, "total_memory_bytes": mem.value}
+
+    def copy_bandwidth_gbps(self, nbytes: int = 1 << 30, repeats: int = 10) -> float:
+        g = C.c_double()
+        _check(load_library().grx_measure_copy_bandwidth(self._h, nbytes, repeats, g),
+               "grx_measure_copy_bandwidth")
+        return g.value
+
+    def close(self) -> None:
+        if self._h:
+            load_library().grx_context_destroy(self._h)
+            self._h = _VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Graph:
+    """graph::graph_t over CSR (reference graph/build.hxx:26-36); int32 ids, float weights."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+        n, m, nnz = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(load_library().grx_graph_info(self._h, n, m, nnz, None, None, None), "grx_graph_info")
+        self.n_rows, self.n_cols, self.nnz = n.value, m.value, nnz.value
+
+    @staticmethod
+    def from_host_csr(row_offsets, col, val, n_cols=None) -> "Graph":
+        ap = np.ascontiguousarray(row_offsets, np.int32)
+        aj = np.ascontiguousarray(col, np.int32)
+        ax = np.ascontiguousarray(val, np.float32)
+        h = _VP()
+        n = len(ap) - 1
+        _check(load_library().grx_graph_from_host_csr(
+            n, n if n_cols is None else n_cols, len(aj), ap.ctypes.data,
+            aj.ctypes.data if len(aj) else None, ax.ctypes.data if len(ax) else None, C.byref(h)),
+            "grx_graph_from_host_csr")
+        return Graph(h)
+
+    @staticmethod
+    def from_device_csr(row_offsets, col, val) -> "Graph":
+        """Non-owning view over torch int32/int32/float32 device tensors (kept alive here)."""
+        h = _VP()
+        n = row_offsets.numel() - 1
+        _check(load_library().grx_graph_from_device_csr(n, n, col.numel(), _ptr(row_offsets),
+                                                        _ptr(col), _ptr(val), C.byref(h)),
+               "grx_graph_from_device_csr")
+        return Graph(h, keepalive=(row_offsets, col, val))
+
+    @staticmethod
+    def from_mtx(path: str) -> "Graph":
+        h = _VP()
+        _check(load_library().grx_graph_from_mtx(path.encode(), C.byref(h)), "grx_graph_from_mtx")
+        return Graph(h)
+
+    @staticmethod
+    def from_csr_file(path: str) -> "Graph":
+        h = _VP()
+        _check(load_library().grx_graph_from_csr_file(path.encode(), C.byref(h)),
+               "grx_graph_from_csr_file")
+        return Graph(h)
+
+    @staticmethod
+    def rmat(ctx: Context, scale: int, edge_factor: int = 16, seed: int = 1, weight_seed: int = 0,
+             symmetrize: bool = True) -> "Graph":
+        h = _VP()
+        _check(load_library().grx_graph_rmat(ctx._h, scale, edge_factor, seed, weight_seed,
+                                             int(symmetrize), C.byref(h)), "grx_graph_rmat")
+        return Graph(h)
+
+    def write_csr_file(self, path: str) -> None:
+        _check(load_library().grx_graph_write_csr_file(self._h, path.encode()),
+               "grx_graph_write_csr_file")
+
+    def to_host(self):
+        ap = np.empty(self.n_rows + 1, np.int32)
+        aj = np.empty(max(self.nnz, 1), np.int32)
+        ax = np.empty(max(self.nnz, 1), np.float32)
+        _check(load_library().grx_graph_copy_to_host(self._h, ap.ctypes.data, aj.ctypes.data,
+                                                     ax.ctypes.data), "grx_graph_copy_to_host")
+        return ap, aj[: self.nnz], ax[: self.nnz]
+
+    def close(self) -> None:
+        if self._h:
+            load_library().grx_graph_destroy(self._h)
+            self._h = _VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def bfs(ctx: Context, g: Graph, source: int, distances=None, options: Optional[Options] = None):
+    """gunrock::bfs::run -> (int32 depths on the device, Stats)."""
+    torch = _torch()
+    if distances is None:
+        distances = torch.empty(g.n_rows, dtype=torch.int32, device=f"cuda:{ctx.device}")
+    o = (options or Options())._c()
+    s = _Stats()
+    _check(load_library().grx_bfs(ctx._h, g._h, source, _ptr(distances), None, C.byref(o),
+                                  C.byref(s)), "grx_bfs")
+    return distances, Stats._from(s)
+
+
+def sssp(ctx: Context, g: Graph, source: int, distances=None, options: Optional[Options] = None):
+    """gunrock::sssp::run -> (float32 distances on the device, Stats)."""
+    torch = _torch()
+    if distances is None:
+        distances = torch.empty(g.n_rows, dtype=torch.float32, device=f"cuda:{ctx.device}")
+    o = (options or Options())._c()
+    s = _Stats()
+    _check(load_library().grx_sssp(ctx._h, g._h, source, _ptr(distances), None, C.byref(o),
+                                   C.byref(s)), "grx_sssp")
+    return distances, Stats._from(s)
+
+
+def pagerank(ctx: Context, g: Graph, alpha: float = 0.85, tol: float = 1e-6, p=None,
+             options: Optional[Options] = None):
+    """gunrock::pr::run -> (float32 ranks on the device, Stats)."""
+    torch = _torch()
+    if p is None:
+        p = torch.empty(g.n_rows, dtype=torch.float32, device=f"cuda:{ctx.device}")
+    o = (options or Options())._c()
+    s = _Stats()
+    _check(load_library().grx_pagerank(ctx._h, g._h, alpha, tol, _ptr(p), C.byref(o), C.byref(s)),
+           "grx_pagerank")
+    return p, Stats._from(s)
+
+
+def advance(ctx: Context, g: Graph, frontier, op: EdgeOp = EdgeOp.all, state=None, iparam: int = 0,
+            options: Optional[Options] = None, want_output: bool = True,
+            capacity: Optional[int] = None):
+    """operators::advance::execute (frontier overload).  frontier=None -> whole graph.
+
+    Returns the output frontier (int32 device tensor, order unspecified) or None.
+    """
+    torch = _torch()
+    o = (options or Options())._c()
+    n_in = 0 if frontier is None else frontier.numel()
+    out = None
+    cap = 0
+    if want_output:
+        cap = capacity if capacity is not None else max(int(g.nnz) * 2 + 16, 16)
+        out = torch.empty(cap, dtype=torch.int32, device=f"cuda:{ctx.device}")
+    n_out = C.c_int64()
+    _check(load_library().grx_advance(ctx._h, g._h, C.byref(o), int(op), _ptr(state), iparam,
+                                      _ptr(frontier), n_in, _ptr(out), cap, C.byref(n_out)),
+           "grx_advance")
+    return out[: n_out.value] if want_output else None
+
+
+def filter(ctx: Context, g: Graph, frontier, algorithm: FilterAlgorithm,
+           pred: VertexOp = VertexOp.all, state=None, iparam: int = 0):
+    """operators::filter::execute (frontier overload) -> new frontier tensor."""
+    torch = _torch()
+    n_in = frontier.numel()
+    out = torch.empty(max(n_in, 1), dtype=torch.int32, device=f"cuda:{ctx.device}")
+    n_out = C.c_int64()
+    _check(load_library().grx_filter(ctx._h, g._h, int(algorithm), int(pred), _ptr(state), iparam,
+                                     _ptr(frontier) if n_in else None, n_in, _ptr(out),
+                                     out.numel(), C.byref(n_out)), "grx_filter")
+    return out[: n_out.value]
+
+
+def uniquify(ctx: Context, frontier, algorithm: UniquifyAlgorithm = UniquifyAlgorithm.unique,
+             best_effort: bool = False):
+    """operators::uniquify::execute (frontier overload) -> deduplicated frontier tensor."""
+    torch = _torch()
+    n_in = frontier.numel()
+    work = frontier.clone()
+    out = torch.empty(max(n_in, 1), dtype=torch.int32, device=f"cuda:{ctx.device}")
+    n_out = C.c_int64()
+    _check(load_library().grx_uniquify(ctx._h, int(algorithm), int(best_effort),
+                                       _ptr(work) if n_in else None, n_in, _ptr(out), out.numel(),
+                                       C.byref(n_out)), "grx_uniquify")
+    res = work if algorithm == UniquifyAlgorithm.unique else out
+    return res[: n_out.value]

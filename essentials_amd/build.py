@@ -1,0 +1,86 @@
+"""Build libessentials_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m essentials_amd.build [--force] [--jobs N]
+
+Every ``essentials_amd/csrc/*.hip`` is compiled to an object under
+``essentials_amd/csrc/build/`` and linked into ``essentials_amd/libessentials_amd.so``.
+hipcc cross-compiles for gfx950 without a GPU.  The library travels to the GPU
+box as a built artefact (git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(PKG, "libessentials_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+FLAGS = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC", "-I", os.path.join(ROOT, "include"),
+         "-Wno-unused-result", "-Wno-inconsistent-missing-override"]
+
+
+def _headers():
+    hs = glob.glob(os.path.join(ROOT, "include", "**", "*.hxx"), recursive=True)
+    hs += glob.glob(os.path.join(ROOT, "include", "*.h"))
+    hs += glob.glob(os.path.join(CSRC, "*.hxx"))
+    return hs
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths) if paths else 0.0
+
+
+def _compile(src, obj):
+    cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {os.path.basename(src)}:\n{r.stderr[-6000:]}")
+    return obj
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdr_time = _newest(_headers())
+    todo, objs = [], []
+    for s in sources:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            todo.append((s, o))
+    if todo:
+        if verbose:
+            print(f"[build] compiling {len(todo)} HIP sources for {ARCH}", flush=True)
+        jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2)))
+        with ThreadPoolExecutor(jobs) as ex:
+            list(ex.map(lambda so: _compile(*so), todo))
+    if todo or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    try:
+        print(build(a.force, a.jobs, verbose=True))
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

@@ -1,0 +1,47 @@
+/** @file capi_bfs.hip  grx_bfs == gunrock::bfs::run (reference algorithms/bfs.hxx:151-176). */
+#include "capi_internal.hxx"
+#include "clients.hxx"
+
+using namespace essentials_amd;
+
+extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t* d_distances,
+                       int32_t* /*d_predecessors*/, const grx_options* opt, grx_stats* stats) {
+  if (!ctx || !g || !d_distances)
+    return invalid("grx_bfs: NULL argument");
+  if (source < 0 || source >= g->n_rows)
+    return invalid("grx_bfs: source out of range");
+  grx_options o;
+  grx_default_options(&o);
+  if (opt)
+    o = *opt;
+  return guarded([&] {
+    return with_load_balance(o.load_balance, [&](auto lb_tag) -> int {
+      constexpr auto lb = decltype(lb_tag)::value;
+      using problem_type = clients::bfs_problem_t<graph_type>;
+      using enactor_type = clients::bfs_enactor_t<problem_type, lb>;
+      scoped_options scope(ctx->single(), &o);
+      graph_type G = g->view();
+      problem_type problem(G, source, d_distances, ctx->mc);
+      problem.init();
+      problem.reset();
+      enactor_properties_t props;
+      if (o.frontier_sizing_factor > 0)
+        props.frontier_sizing_factor = o.frontier_sizing_factor;
+      enactor_type enactor(&problem, ctx->mc, props);
+      enactor.max_iterations = o.max_iterations;
+      const float ms = enactor.enact();
+      if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->elapsed_ms = ms;
+        stats->iterations = enactor.iteration;
+        stats->advance_kernel_ms = ctx->single().kernel_clock().total_ms;
+        stats->advance_launches = ctx->single().kernel_clock().launches;
+        stats->levels_recorded = problem.log.levels < 64 ? problem.log.levels : 64;
+        for (int i = 0; i < stats->levels_recorded; ++i)
+          stats->frontier_slots[i] = problem.log.input_slots[i];
+        reach_stats(g, d_distances, INT32_MAX, ctx->single(), stats);
+      }
+      return (int)GRX_OK;
+    });
+  });
+}

@@ -1,0 +1,232 @@
+/**
+ * @file capi_core.hip
+ * @brief C ABI: library, context, graph construction / IO, bandwidth probe.
+ * See include/essentials_amd.h for the reference interface each entry stands for.
+ */
+#include "capi_internal.hxx"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace essentials_amd {
+std::string& last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
+}  // namespace essentials_amd
+
+using namespace essentials_amd;
+
+extern "C" {
+
+int grx_abi_version(void) { return GRX_ABI_VERSION; }
+const char* grx_last_error(void) { return last_error().c_str(); }
+
+void grx_default_options(grx_options* opt) {
+  if (!opt)
+    return;
+  std::memset(opt, 0, sizeof *opt);
+  opt->load_balance = GRX_LB_BLOCK_MAPPED;
+  opt->frontier_sizing_factor = 1.5f;
+}
+
+int grx_context_create(int device, void* stream, grx_context_t* out) {
+  if (!out)
+    return invalid("grx_context_create: out is NULL");
+  return guarded([&] {
+    int count = 0;
+    GRX_HIP_CHECK(hipGetDeviceCount(&count));
+    error::throw_if_exception(device < 0 || device >= count, "grx_context_create: no such device");
+    auto* c = new grx_context_s;
+    c->device = device;
+    if (stream)
+      c->mc = std::make_shared<gcuda::multi_context_t>(device, (hipStream_t)stream);
+    else
+      c->mc = std::make_shared<gcuda::multi_context_t>(device);
+    *out = c;
+    return (int)GRX_OK;
+  });
+}
+
+int grx_context_destroy(grx_context_t ctx) {
+  if (!ctx)
+    return GRX_OK;
+  return guarded([&] {
+    delete ctx;
+    return (int)GRX_OK;
+  });
+}
+
+int grx_context_synchronize(grx_context_t ctx) {
+  if (!ctx)
+    return invalid("context is NULL");
+  return guarded([&] {
+    ctx->single().synchronize();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_context_device_info(grx_context_t ctx, int32_t* cus, int32_t* wave, int64_t* mem,
+                            char* name, size_t name_len) {
+  if (!ctx)
+    return invalid("context is NULL");
+  const hipDeviceProp_t& p = ctx->single().props();
+  if (cus) *cus = p.multiProcessorCount;
+  if (wave) *wave = p.warpSize;
+  if (mem) *mem = (int64_t)p.totalGlobalMem;
+  if (name && name_len) {
+    std::strncpy(name, p.name, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return GRX_OK;
+}
+
+// ---- graphs ------------------------------------------------------------------
+
+int grx_graph_from_device_csr(int32_t n_rows, int32_t n_cols, int32_t nnz, const int32_t* d_ap,
+                              const int32_t* d_aj, const float* d_ax, grx_graph_t* out) {
+  if (!out || n_rows < 0 || nnz < 0 || !d_ap || (nnz && (!d_aj || !d_ax)))
+    return invalid("grx_graph_from_device_csr: bad arguments");
+  return guarded([&] {
+    auto* g = new grx_graph_s;
+    g->n_rows = n_rows; g->n_cols = n_cols; g->nnz = nnz;
+    g->d_ap = d_ap; g->d_aj = d_aj; g->d_ax = d_ax;
+    *out = g;
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_from_host_csr(int32_t n_rows, int32_t n_cols, int32_t nnz, const int32_t* h_ap,
+                            const int32_t* h_aj, const float* h_ax, grx_graph_t* out) {
+  if (!out || n_rows < 0 || nnz < 0 || !h_ap || (nnz && (!h_aj || !h_ax)))
+    return invalid("grx_graph_from_host_csr: bad arguments");
+  return guarded([&] {
+    auto g = std::make_unique<grx_graph_s>();
+    g->n_rows = n_rows; g->n_cols = n_cols; g->nnz = nnz;
+    g->ap.assign(h_ap, (std::size_t)n_rows + 1);
+    g->aj.assign(h_aj, (std::size_t)nnz);
+    g->ax.assign(h_ax, (std::size_t)nnz);
+    g->adopt();
+    *out = g.release();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_from_mtx(const char* path, grx_graph_t* out) {
+  if (!out || !path)
+    return invalid("grx_graph_from_mtx: bad arguments");
+  return guarded([&] {
+    io::matrix_market_t<vertex_t, edge_t, weight_t> mm;
+    format::csr_t<memory_space_t::host, vertex_t, edge_t, weight_t> csr;
+    csr.from_coo(mm.load(path));
+    return grx_graph_from_host_csr(csr.number_of_rows, csr.number_of_columns, csr.number_of_nonzeros,
+                                   csr.row_offsets.data(), csr.column_indices.data(),
+                                   csr.nonzero_values.data(), out);
+  });
+}
+
+int grx_graph_from_csr_file(const char* path, grx_graph_t* out) {
+  if (!out || !path)
+    return invalid("grx_graph_from_csr_file: bad arguments");
+  return guarded([&] {
+    format::csr_t<memory_space_t::host, vertex_t, edge_t, weight_t> csr;
+    csr.read_binary(path);
+    return grx_graph_from_host_csr(csr.number_of_rows, csr.number_of_columns, csr.number_of_nonzeros,
+                                   csr.row_offsets.data(), csr.column_indices.data(),
+                                   csr.nonzero_values.data(), out);
+  });
+}
+
+int grx_graph_copy_to_host(grx_graph_t g, int32_t* h_ap, int32_t* h_aj, float* h_ax) {
+  if (!g)
+    return invalid("graph is NULL");
+  return guarded([&] {
+    if (h_ap)
+      GRX_HIP_CHECK(hipMemcpy(h_ap, g->d_ap, ((std::size_t)g->n_rows + 1) * 4, hipMemcpyDeviceToHost));
+    if (h_aj && g->nnz)
+      GRX_HIP_CHECK(hipMemcpy(h_aj, g->d_aj, (std::size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+    if (h_ax && g->nnz)
+      GRX_HIP_CHECK(hipMemcpy(h_ax, g->d_ax, (std::size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_write_csr_file(grx_graph_t g, const char* path) {
+  if (!g || !path)
+    return invalid("grx_graph_write_csr_file: bad arguments");
+  return guarded([&] {
+    std::vector<int32_t> ap((std::size_t)g->n_rows + 1), aj((std::size_t)g->nnz);
+    std::vector<float> ax((std::size_t)g->nnz);
+    int rc = grx_graph_copy_to_host(g, ap.data(), aj.data(), ax.data());
+    if (rc)
+      return rc;
+    FILE* f = std::fopen(path, "wb");
+    error::throw_if_exception(f == nullptr, std::string("cannot open ") + path);
+    int32_t nnz32 = (int32_t)g->nnz;
+    std::fwrite(&g->n_rows, 4, 1, f);
+    std::fwrite(&g->n_cols, 4, 1, f);
+    std::fwrite(&nnz32, 4, 1, f);
+    std::fwrite(ap.data(), 4, ap.size(), f);
+    std::fwrite(aj.data(), 4, aj.size(), f);
+    std::fwrite(ax.data(), 4, ax.size(), f);
+    std::fclose(f);
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_destroy(grx_graph_t g) {
+  if (!g)
+    return GRX_OK;
+  return guarded([&] {
+    delete g;
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_info(grx_graph_t g, int32_t* n_rows, int32_t* n_cols, int64_t* nnz,
+                   const int32_t** d_ap, const int32_t** d_aj, const float** d_ax) {
+  if (!g)
+    return invalid("graph is NULL");
+  if (n_rows) *n_rows = g->n_rows;
+  if (n_cols) *n_cols = g->n_cols;
+  if (nnz) *nnz = g->nnz;
+  if (d_ap) *d_ap = g->d_ap;
+  if (d_aj) *d_aj = g->d_aj;
+  if (d_ax) *d_ax = g->d_ax;
+  return GRX_OK;
+}
+
+// ---- achievable-HBM roof -----------------------------------------------------
+
+namespace {
+__global__ void __launch_bounds__(256) copy16_kernel(const uint4* __restrict__ in,
+                                                     uint4* __restrict__ out, std::size_t n) {
+  for (std::size_t i = blockIdx.x * (std::size_t)256 + threadIdx.x; i < n;
+       i += (std::size_t)gridDim.x * 256)
+    out[i] = in[i];
+}
+}  // namespace
+
+int grx_measure_copy_bandwidth(grx_context_t ctx, size_t bytes, int repeats, double* gbps) {
+  if (!ctx || !gbps || bytes < 4096 || repeats < 1)
+    return invalid("grx_measure_copy_bandwidth: bad arguments");
+  return guarded([&] {
+    auto& c = ctx->single();
+    const std::size_t n = bytes / 16;
+    hip::buffer_t<uint4> a(n), b(n);
+    GRX_HIP_CHECK(hipMemsetAsync(a.data(), 1, n * 16, c.stream()));
+    copy16_kernel<<<(unsigned)c.compute_units() * 8, 256, 0, c.stream()>>>(a.data(), b.data(), n);
+    c.synchronize();
+    util::timer_t t(c.stream());
+    t.begin();
+    for (int r = 0; r < repeats; ++r)
+      copy16_kernel<<<(unsigned)c.compute_units() * 8, 256, 0, c.stream()>>>(a.data(), b.data(), n);
+    GRX_HIP_CHECK(hipGetLastError());
+    float ms = t.end();
+    *gbps = (2.0 * (double)n * 16.0 * repeats) / ((double)ms * 1e-3) / 1e9;  // read + write
+    return (int)GRX_OK;
+  });
+}
+
+}  // extern "C"

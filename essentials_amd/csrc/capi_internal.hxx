@@ -1,0 +1,147 @@
+/**
+ * @file capi_internal.hxx
+ * @brief Shared definitions of the C-ABI translation units (not installed).
+ */
+#pragma once
+
+#include <cfloat>
+#include <climits>
+#include <memory>
+#include <string>
+
+#include <gunrock/algorithms/algorithms.hxx>
+#include <gunrock/hip/algorithms.hxx>
+
+#include "../../include/essentials_amd.h"
+
+namespace essentials_amd {
+
+using namespace gunrock;
+
+using vertex_t = int32_t;
+using edge_t = int32_t;
+using weight_t = float;
+
+using graph_type = decltype(graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+    vertex_t(0), vertex_t(0), edge_t(0), (edge_t*)nullptr, (vertex_t*)nullptr, (weight_t*)nullptr));
+using frontier_type = frontier::frontier_t<vertex_t, edge_t>;
+
+std::string& last_error();
+
+/// Run `body`, translating the C++ surface's exceptions into status codes.
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const error::exception_t& e) {
+    last_error() = e.what();
+    return GRX_ERR_RUNTIME;
+  } catch (const std::exception& e) {
+    last_error() = e.what();
+    return GRX_ERR_RUNTIME;
+  } catch (...) {
+    last_error() = "unknown exception";
+    return GRX_ERR_RUNTIME;
+  }
+}
+
+inline int invalid(const char* why) {
+  last_error() = why;
+  return GRX_ERR_INVALID_ARGUMENT;
+}
+inline int unsupported(const char* why) {
+  last_error() = why;
+  return GRX_ERR_UNSUPPORTED;
+}
+
+}  // namespace essentials_amd
+
+struct grx_context_s {
+  std::shared_ptr<gunrock::gcuda::multi_context_t> mc;
+  int device = 0;
+  void* comm = nullptr;  // ncclComm_t when attached to a job
+  int rank = 0;
+  int world = 1;
+  gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
+};
+
+struct grx_graph_s {
+  int32_t n_rows = 0, n_cols = 0;
+  int64_t nnz = 0;
+  // owning storage (empty for a view over caller memory)
+  gunrock::hip::device_array_t<int32_t> ap, aj;
+  gunrock::hip::device_array_t<float> ax;
+  const int32_t* d_ap = nullptr;
+  const int32_t* d_aj = nullptr;
+  const float* d_ax = nullptr;
+
+  essentials_amd::graph_type view() const {
+    using namespace gunrock;
+    return graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+        n_rows, n_cols, (int32_t)nnz, const_cast<int32_t*>(d_ap), const_cast<int32_t*>(d_aj),
+        const_cast<float*>(d_ax));
+  }
+  void adopt() {
+    d_ap = ap.data();
+    d_aj = aj.data();
+    d_ax = ax.data();
+  }
+};
+
+namespace essentials_amd {
+
+/// Apply grx_options to the context for the duration of a call.
+struct scoped_options {
+  gcuda::standard_context_t& ctx;
+  gcuda::operator_options_t saved;
+  scoped_options(gcuda::standard_context_t& c, const grx_options* opt) : ctx(c), saved(c.options()) {
+    if (opt) {
+      ctx.options().holes_layout = opt->holes_layout != 0;
+      if (opt->hub_threshold > 0)
+        ctx.options().hub_threshold = (unsigned)opt->hub_threshold;
+      ctx.options().time_kernels = opt->collect_kernel_time != 0;
+    }
+    ctx.kernel_clock().reset();
+  }
+  ~scoped_options() { ctx.options() = saved; }
+};
+
+/// Dispatch a run-time grx_load_balance onto a compile-time load_balance_t.
+template <typename F>
+int with_load_balance(int lb, F&& f) {
+  using operators::load_balance_t;
+  switch (lb) {
+    case GRX_LB_THREAD_MAPPED: return f(std::integral_constant<load_balance_t, load_balance_t::thread_mapped>());
+    case GRX_LB_WARP_MAPPED: return f(std::integral_constant<load_balance_t, load_balance_t::warp_mapped>());
+    case GRX_LB_BLOCK_MAPPED: return f(std::integral_constant<load_balance_t, load_balance_t::block_mapped>());
+    case GRX_LB_BUCKETING: return f(std::integral_constant<load_balance_t, load_balance_t::bucketing>());
+    case GRX_LB_MERGE_PATH:
+    case GRX_LB_MERGE_PATH_V2: return f(std::integral_constant<load_balance_t, load_balance_t::merge_path>());
+    case GRX_LB_WORK_STEALING: return f(std::integral_constant<load_balance_t, load_balance_t::work_stealing>());
+    default: return invalid("unknown load_balance");
+  }
+}
+
+/// vertices_reached / edges_traversed from a label array (outside the timed region).
+template <typename label_t>
+void reach_stats(grx_graph_s* g, const label_t* d_labels, label_t unreached,
+                 gcuda::standard_context_t& ctx, grx_stats* stats) {
+  if (!stats)
+    return;
+  const int32_t* ap = g->d_ap;
+  const std::size_t n = (std::size_t)g->n_rows;
+  stats->vertices_reached = (int64_t)hip::transform_reduce(
+      n,
+      [d_labels, unreached] __device__(std::size_t i) -> unsigned long long {
+        return d_labels[i] != unreached ? 1ull : 0ull;
+      },
+      0ull, rocprim::plus<unsigned long long>(), ctx);
+  stats->edges_traversed = (int64_t)hip::transform_reduce(
+      n,
+      [d_labels, unreached, ap] __device__(std::size_t i) -> unsigned long long {
+        return d_labels[i] != unreached ? (unsigned long long)(ap[i + 1] - ap[i]) : 0ull;
+      },
+      0ull, rocprim::plus<unsigned long long>(), ctx);
+}
+
+}  // namespace essentials_amd

@@ -1,0 +1,304 @@
+/**
+ * @file clients.hxx
+ * @brief The build's own BFS / SSSP / PageRank written against the engine's
+ * public API -- the conformance clients that travel to the GPU box (the
+ * reference's algorithm headers cannot).
+ *
+ * They exercise exactly the call forms the reference's clients use
+ * (SURVEY.md 8b): problem_t / enactor_t subclasses, prepare_frontier ->
+ * push_back, operators::advance::execute<lb>(G, E, op, context) with a
+ * bool(vertex const&, vertex const&, edge const&, weight const&) functor,
+ * operators::filter::execute<bypass>(G, E, pred, context), the 4-argument
+ * <lb, forward, graph, none> advance, math::atomic::{min,add}, thread::load,
+ * enactor_properties_t::self_manage_frontiers, enact() -> ms.
+ * Algorithms: reference algorithms/bfs.hxx:80-132, sssp.hxx:98-151,
+ * pr.hxx:64-178.  Independently written; the schedule is a template parameter.
+ */
+#pragma once
+
+#include <gunrock/framework/framework.hxx>
+#include <gunrock/hip/algorithms.hxx>
+
+namespace essentials_amd {
+namespace clients {
+
+using namespace gunrock;
+using operators::load_balance_t;
+
+/// Per-run record filled by the enactors (host side, no device cost).
+struct level_log_t {
+  static constexpr int max_levels = 64;
+  int levels = 0;
+  long long input_slots[max_levels] = {0};
+  void note(std::size_t slots) {
+    if (levels < max_levels)
+      input_slots[levels] = (long long)slots;
+    ++levels;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// breadth-first search: depth[v] = hops from the source, INT_MAX if unreachable
+// ---------------------------------------------------------------------------
+template <typename graph_t>
+struct bfs_problem_t : gunrock::problem_t<graph_t> {
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+
+  vertex_t source;
+  vertex_t* depth;  // device, |V|, caller-owned
+  level_log_t log;
+
+  bfs_problem_t(graph_t& G, vertex_t _source, vertex_t* _depth,
+                std::shared_ptr<gcuda::multi_context_t> ctx)
+      : gunrock::problem_t<graph_t>(G, ctx), source(_source), depth(_depth) {}
+
+  void init() override {}
+  void reset() override {
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    hip::fill(depth, n, std::numeric_limits<vertex_t>::max(), ctx->stream());
+    hip::fill(depth + source, 1, vertex_t(0), ctx->stream());
+    ctx->synchronize();
+    log = level_log_t();
+  }
+};
+
+template <typename problem_type, load_balance_t lb>
+struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
+  using base_t = gunrock::enactor_t<problem_type>;
+  using vertex_t = typename problem_type::vertex_t;
+  using edge_t = typename problem_type::edge_t;
+  using weight_t = typename problem_type::weight_t;
+  using frontier_t = typename base_t::frontier_t;
+  int max_iterations = 0;
+
+  bfs_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
+                enactor_properties_t props = enactor_properties_t())
+      : base_t(p, ctx, props) {}
+
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
+    f->push_back(this->get_problem()->source);
+  }
+
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (max_iterations && this->iteration >= max_iterations)
+      return true;
+    return base_t::is_converged(context);
+  }
+
+  void loop(gcuda::multi_context_t& context) override {
+    auto E = this->get_enactor();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    P->log.note(E->get_input_frontier()->get_number_of_elements());
+
+    vertex_t* depth = P->depth;
+    const vertex_t next_level = this->iteration + 1;
+    auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                         edge_t const& edge,
+                                                         weight_t const& weight) -> bool {
+      // first arrival wins; later arrivals of the same level see an equal depth
+      return next_level < math::atomic::min(&depth[dst], next_level);
+    };
+    operators::advance::execute<lb>(G, E, visit, context);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// single-source shortest paths (Bellman-Ford style frontier relaxation)
+// ---------------------------------------------------------------------------
+template <typename graph_t>
+struct sssp_problem_t : gunrock::problem_t<graph_t> {
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+
+  vertex_t source;
+  weight_t* distance;  // device, |V|, caller-owned
+  hip::device_array_t<int> stamp;  // iteration in which a vertex last entered the frontier
+  level_log_t log;
+
+  sssp_problem_t(graph_t& G, vertex_t _source, weight_t* _distance,
+                 std::shared_ptr<gcuda::multi_context_t> ctx)
+      : gunrock::problem_t<graph_t>(G, ctx), source(_source), distance(_distance) {}
+
+  void init() override {
+    stamp.resize((std::size_t)this->get_graph().get_number_of_vertices());
+  }
+  void reset() override {
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    hip::fill(distance, n, std::numeric_limits<weight_t>::max(), ctx->stream());
+    hip::fill(distance + source, 1, weight_t(0), ctx->stream());
+    hip::fill(stamp.data(), n, -1, ctx->stream());
+    ctx->synchronize();
+    log = level_log_t();
+  }
+};
+
+template <typename problem_type, load_balance_t lb>
+struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
+  using base_t = gunrock::enactor_t<problem_type>;
+  using vertex_t = typename problem_type::vertex_t;
+  using edge_t = typename problem_type::edge_t;
+  using weight_t = typename problem_type::weight_t;
+  using frontier_t = typename base_t::frontier_t;
+  int max_iterations = 0;
+
+  sssp_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
+                 enactor_properties_t props = enactor_properties_t())
+      : base_t(p, ctx, props) {}
+
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
+    f->push_back(this->get_problem()->source);
+  }
+
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (max_iterations && this->iteration >= max_iterations)
+      return true;
+    return base_t::is_converged(context);
+  }
+
+  void loop(gcuda::multi_context_t& context) override {
+    auto E = this->get_enactor();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    P->log.note(E->get_input_frontier()->get_number_of_elements());
+
+    weight_t* distance = P->distance;
+    int* stamp = P->stamp.data();
+    const int round = this->iteration;
+
+    auto relax = [distance] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                edge_t const& edge, weight_t const& w) -> bool {
+      weight_t through = thread::load(&distance[src]) + w;
+      return through < math::atomic::min(&distance[dst], through);
+    };
+    // keep one copy of a vertex per round (benign race: a duplicate may survive)
+    auto once_per_round = [stamp, round] __host__ __device__(vertex_t const& v) -> bool {
+      if (stamp[v] == round)
+        return false;
+      stamp[v] = round;
+      return true;
+    };
+    operators::advance::execute<lb>(G, E, relax, context);
+    operators::filter::execute<operators::filter_algorithm_t::bypass>(G, E, once_per_round, context);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// PageRank, push formulation with dangling-mass redistribution
+// ---------------------------------------------------------------------------
+template <typename graph_t>
+struct pr_problem_t : gunrock::problem_t<graph_t> {
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+
+  weight_t alpha, tol;
+  weight_t* rank;  // device, |V|, caller-owned
+  hip::device_array_t<weight_t> previous;
+  hip::device_array_t<weight_t> out_scale;  // alpha / (sum of out-weights), 0 for dangling
+
+  pr_problem_t(graph_t& G, weight_t _alpha, weight_t _tol, weight_t* _rank,
+               std::shared_ptr<gcuda::multi_context_t> ctx)
+      : gunrock::problem_t<graph_t>(G, ctx), alpha(_alpha), tol(_tol), rank(_rank) {}
+
+  void init() override {
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    previous.resize(n);
+    out_scale.resize(n);
+  }
+  void reset() override {
+    auto ctx = this->get_single_context();
+    auto g = this->get_graph();
+    const std::size_t n = (std::size_t)g.get_number_of_vertices();
+    hip::fill(rank, n, (weight_t)(1.0 / (double)n), ctx->stream());
+    hip::fill(previous.data(), n, weight_t(0), ctx->stream());
+    weight_t* scale = out_scale.data();
+    const weight_t a = alpha;
+    hip::for_each_index(
+        n,
+        [g, scale, a] __device__(std::size_t i) {
+          weight_t total = 0;
+          const edge_t begin = g.get_starting_edge((vertex_t)i);
+          const edge_t end = begin + g.get_number_of_neighbors((vertex_t)i);
+          for (edge_t e = begin; e < end; ++e)
+            total += g.get_edge_weight(e);
+          scale[i] = total != 0 ? a / total : weight_t(0);
+        },
+        ctx->stream());
+    ctx->synchronize();
+  }
+};
+
+template <typename problem_type, load_balance_t lb>
+struct pr_enactor_t : gunrock::enactor_t<problem_type> {
+  using base_t = gunrock::enactor_t<problem_type>;
+  using vertex_t = typename problem_type::vertex_t;
+  using edge_t = typename problem_type::edge_t;
+  using weight_t = typename problem_type::weight_t;
+  int max_iterations = 0;
+
+  pr_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
+               enactor_properties_t props)
+      : base_t(p, ctx, props) {}
+
+  void loop(gcuda::multi_context_t& context) override {
+    auto E = this->get_enactor();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    auto ctx = context.get_context(0);
+    const std::size_t n = (std::size_t)G.get_number_of_vertices();
+    weight_t* rank = P->rank;
+    weight_t* previous = P->previous.data();
+    weight_t* scale = P->out_scale.data();
+    const weight_t alpha = P->alpha;
+
+    GRX_HIP_CHECK(hipMemcpyAsync(previous, rank, n * sizeof(weight_t), hipMemcpyDeviceToDevice,
+                                 ctx->stream()));
+    const weight_t dangling = hip::transform_reduce(
+        n,
+        [rank, scale, alpha] __device__(std::size_t i) -> weight_t {
+          return scale[i] == 0 ? alpha * rank[i] : weight_t(0);
+        },
+        weight_t(0), rocprim::plus<weight_t>(), *ctx);
+    hip::fill(rank, n, (1 - alpha + dangling) / (weight_t)n, ctx->stream());
+
+    auto spread = [rank, previous, scale] __host__ __device__(vertex_t const& src,
+                                                              vertex_t const& dst,
+                                                              edge_t const& edge,
+                                                              weight_t const& w) -> bool {
+      math::atomic::add(rank + dst, previous[src] * scale[src] * w);
+      return false;
+    };
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::graph,
+                                operators::advance_io_type_t::none>(G, E, spread, context);
+  }
+
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (this->iteration == 0)
+      return false;
+    if (max_iterations && this->iteration >= max_iterations)
+      return true;
+    auto P = this->get_problem();
+    auto ctx = context.get_context(0);
+    const std::size_t n = (std::size_t)P->get_graph().get_number_of_vertices();
+    weight_t* rank = P->rank;
+    weight_t* previous = P->previous.data();
+    const weight_t err = hip::transform_reduce(
+        n,
+        [rank, previous] __device__(std::size_t i) -> weight_t {
+          weight_t d = rank[i] - previous[i];
+          return d < 0 ? -d : d;
+        },
+        weight_t(0), rocprim::maximum<weight_t>(), *ctx);
+    return err < P->tol;
+  }
+};
+
+}  // namespace clients
+}  // namespace essentials_amd

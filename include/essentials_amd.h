@@ -1,0 +1,219 @@
+/*
+ * essentials_amd.h -- C ABI of the MI355X-native frontier advance/filter engine.
+ *
+ * The reference (jdwapman/essentials) is a header-only C++ template library with
+ * NO C ABI, FFI or plugin interface: its drop-in boundary is the template surface
+ * under include/gunrock/ (this repository ships its own implementation of that
+ * surface in include/gunrock/, against which the reference's bfs.hxx / sssp.hxx /
+ * pr.hxx compile unchanged).  This header is therefore an ADDITION: the boundary
+ * a non-C++ host (ctypes, cgo, JNI, ...) binds, with the engine's templates
+ * pre-instantiated for the reference harnesses' types
+ *     vertex_t = edge_t = int32_t, weight_t = float
+ * (examples/algorithms/bfs/bfs.cu:16-18).  Each entry point names the reference
+ * interface it stands for.  Conventions:
+ *   - plain pointers and sizes only; every "d_" pointer is DEVICE memory owned by
+ *     the caller (hipMalloc / a torch tensor's data_ptr), every "h_" pointer host;
+ *   - return value 0 on success, a negative grx_status otherwise;
+ *     grx_last_error() returns the message of the calling thread's last failure
+ *     (the C++ surface throws gunrock::error::exception_t, reference error.hxx:21-46);
+ *   - calls on one context are synchronous with respect to the host, like the
+ *     reference's operators (advance/block_mapped.hxx:204);
+ *   - one context per host thread; independent contexts do not share state
+ *     (reference operators/batch/batch.hxx:69-74 relies on that).
+ */
+#ifndef ESSENTIALS_AMD_H
+#define ESSENTIALS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRX_ABI_VERSION 1
+
+typedef enum grx_status {
+  GRX_OK = 0,
+  GRX_ERR_INVALID_ARGUMENT = -1,
+  GRX_ERR_RUNTIME = -2,      /* HIP / RCCL failure or an engine exception */
+  GRX_ERR_UNSUPPORTED = -3   /* variant not implemented (reference: "... not supported") */
+} grx_status;
+
+/* operators::load_balance_t (reference framework/operators/configs.hxx:31-39), same order */
+typedef enum grx_load_balance {
+  GRX_LB_THREAD_MAPPED = 0,
+  GRX_LB_WARP_MAPPED = 1,
+  GRX_LB_BLOCK_MAPPED = 2,
+  GRX_LB_BUCKETING = 3,
+  GRX_LB_MERGE_PATH = 4,
+  GRX_LB_MERGE_PATH_V2 = 5,
+  GRX_LB_WORK_STEALING = 6
+} grx_load_balance;
+
+/* operators::filter_algorithm_t (configs.hxx:73-78), same order */
+typedef enum grx_filter_algorithm {
+  GRX_FILTER_REMOVE = 0,
+  GRX_FILTER_PREDICATED = 1,
+  GRX_FILTER_COMPACT = 2,
+  GRX_FILTER_BYPASS = 3
+} grx_filter_algorithm;
+
+/* operators::uniquify_algorithm_t (configs.hxx:80-85) */
+typedef enum grx_uniquify_algorithm { GRX_UNIQUE = 0, GRX_UNIQUE_COPY = 1 } grx_uniquify_algorithm;
+
+/* Built-in per-edge functors for grx_advance (device lambdas cannot cross a C ABI).
+ * `state` / `iparam` are the functor's captured values. */
+typedef enum grx_edge_op {
+  GRX_OP_ALL = 0,        /* return true                                                     */
+  GRX_OP_BFS = 1,        /* state: int32 depth[V]; it+1 < atomic::min(&depth[dst], it+1), it=iparam
+                            (reference algorithms/bfs.hxx:92-114)                           */
+  GRX_OP_SSSP = 2,       /* state: float dist[V]; d = dist[src]+w; d < atomic::min(&dist[dst], d)
+                            (reference algorithms/sssp.hxx:110-124)                         */
+  GRX_OP_COUNT_EDGE = 3, /* state: int32 calls[E]; atomic::add(&calls[edge],1); return (src+dst)%3==0 */
+  GRX_OP_SUM_WEIGHT = 4  /* state: float acc[V]; atomic::add(&acc[dst], w); return false
+                            (shape of reference algorithms/pr.hxx:140-146)                  */
+} grx_edge_op;
+
+/* Built-in predicates for grx_filter. */
+typedef enum grx_vertex_op {
+  GRX_PRED_ALL = 0,      /* return true                                                     */
+  GRX_PRED_ODD = 1,      /* return v & 1                                                    */
+  GRX_PRED_ONCE = 2,     /* state: int32 stamp[V]; stamp[v]==iparam ? false : (stamp[v]=iparam, true)
+                            (reference algorithms/sssp.hxx:126-136)                         */
+  GRX_PRED_COUNT = 3     /* state: int32 calls[V]; atomic::add(&calls[v],1); return v % 3 != 0 */
+} grx_vertex_op;
+
+typedef struct grx_context_s* grx_context_t; /* gcuda::multi_context_t, cuda/context.hxx:136-206 */
+typedef struct grx_graph_s* grx_graph_t;     /* graph::graph_t over CSR, graph/build.hxx:26-36   */
+
+/* enactor_properties_t (framework/enactor.hxx:31-54) + the engine's run-time switches */
+typedef struct grx_options {
+  int32_t load_balance;     /* grx_load_balance; default GRX_LB_BLOCK_MAPPED (what bfs.hxx spells) */
+  int32_t holes_layout;     /* 1: one output slot per traversed edge, -1 holes (reference layout) */
+  int32_t hub_threshold;    /* 0: default (2048)                                                  */
+  int32_t max_iterations;   /* 0: run to convergence                                              */
+  float frontier_sizing_factor; /* 0: default 1.5 (enactor.hxx:36)                                */
+  int32_t collect_kernel_time;  /* 1: event-time the advance kernels (adds two events per launch)  */
+  int32_t reserved[2];
+} grx_options;
+
+/* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the
+ * stats block util/info.hxx:36-71 names but never implemented). */
+typedef struct grx_stats {
+  float elapsed_ms;            /* device-event time around the BSP loop only           */
+  float advance_kernel_ms;     /* sum of advance kernel durations (collect_kernel_time) */
+  int32_t iterations;          /* loop() calls                                         */
+  int32_t advance_launches;    /* advance kernel launches timed                        */
+  int64_t vertices_reached;    /* BFS/SSSP: labels != unreached                        */
+  int64_t edges_traversed;     /* BFS/SSSP: sum of out-degrees of reached vertices     */
+  int32_t levels_recorded;     /* min(iterations, 64)                                  */
+  int32_t reserved;
+  int64_t frontier_slots[64];  /* input-frontier length of each iteration              */
+} grx_stats;
+
+/* ---- library ------------------------------------------------------------- */
+int grx_abi_version(void);
+const char* grx_last_error(void);
+
+/* ---- context: gcuda::multi_context_t(device[, stream]) ------------------- */
+/* stream: a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream) or NULL
+ * for a private non-blocking stream (reference cuda/context.hxx:75-87,163-177). */
+int grx_context_create(int device, void* stream, grx_context_t* out);
+int grx_context_destroy(grx_context_t ctx);
+int grx_context_synchronize(grx_context_t ctx);
+int grx_context_device_info(grx_context_t ctx, int32_t* compute_units, int32_t* wavefront_size,
+                            int64_t* total_memory_bytes, char* name, size_t name_len);
+
+/* ---- graph: graph::build::from_csr<device, view_t::csr> ------------------ */
+/* Non-owning view over caller-owned device CSR arrays (graph/graph.hxx:159-168). */
+int grx_graph_from_device_csr(int32_t n_rows, int32_t n_cols, int32_t nnz,
+                              const int32_t* d_row_offsets, const int32_t* d_col,
+                              const float* d_val, grx_graph_t* out);
+/* Owning device copy of host CSR arrays (format::csr_t<device>, formats/csr.hxx:25-77). */
+int grx_graph_from_host_csr(int32_t n_rows, int32_t n_cols, int32_t nnz,
+                            const int32_t* h_row_offsets, const int32_t* h_col,
+                            const float* h_val, grx_graph_t* out);
+/* Matrix Market file -> owning device CSR (io/matrix_market.hxx:99-240 + csr.hxx:79-157). */
+int grx_graph_from_mtx(const char* path, grx_graph_t* out);
+/* ".csr" binary cache (formats/csr.hxx:159-236). */
+int grx_graph_from_csr_file(const char* path, grx_graph_t* out);
+int grx_graph_write_csr_file(grx_graph_t g, const char* path);
+/* Synthetic R-MAT (no reference counterpart; spec in DESIGN.md, oracle in oracle/grx_oracle.c):
+ * 2^scale vertices, edge_factor*2^scale generated pairs, loader-style symmetrisation when
+ * symmetrize != 0, weights 1.0f when weight_seed == 0 else integers in [1,64]. Built on the GPU. */
+int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_factor, uint64_t seed,
+                   uint64_t weight_seed, int symmetrize, grx_graph_t* out);
+int grx_graph_destroy(grx_graph_t g);
+int grx_graph_info(grx_graph_t g, int32_t* n_rows, int32_t* n_cols, int64_t* nnz,
+                   const int32_t** d_row_offsets, const int32_t** d_col, const float** d_val);
+int grx_graph_copy_to_host(grx_graph_t g, int32_t* h_row_offsets, int32_t* h_col, float* h_val);
+
+/* ---- algorithms: gunrock::{bfs,sssp,pr}::run ------------------------------ */
+void grx_default_options(grx_options* opt);
+/* bfs::run(G, source, distances, predecessors, context)  algorithms/bfs.hxx:151-176.
+ * d_distances: int32[V] out (INT32_MAX = unreached). d_predecessors: unused by the reference
+ * ("@todo", bfs.hxx:28), may be NULL. */
+int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t* d_distances,
+            int32_t* d_predecessors, const grx_options* opt, grx_stats* stats);
+/* sssp::run(G, source, distances, predecessors, context)  algorithms/sssp.hxx:155-185.
+ * d_distances: float[V] out (FLT_MAX = unreached). */
+int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float* d_distances,
+             int32_t* d_predecessors, const grx_options* opt, grx_stats* stats);
+/* pr::run(G, alpha, tol, p, context)  algorithms/pr.hxx:182-216.  d_p: float[V] out. */
+int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float tol, float* d_p,
+                 const grx_options* opt, grx_stats* stats);
+
+/* ---- operators (frontier-level overloads) -------------------------------- */
+/* operators::advance::execute<lb, forward, in, out>(G, op, input, output, segments, context)
+ * (framework/operators/advance/advance.hxx:91-129).
+ *   d_input == NULL  -> advance_io_type_t::graph (all n_rows vertices)
+ *   d_output == NULL -> advance_io_type_t::none
+ * *n_output receives the new number of elements; the output holds them in unspecified
+ * order (block_mapped.hxx:94-101). Fails with GRX_ERR_RUNTIME if output_capacity is too small. */
+int grx_advance(grx_context_t ctx, grx_graph_t g, const grx_options* opt, int32_t edge_op,
+                void* d_state, int32_t iparam, const int32_t* d_input, int64_t n_input,
+                int32_t* d_output, int64_t output_capacity, int64_t* n_output);
+/* operators::filter::execute<alg>(G, op, input, output, context)  filter/filter.hxx:59-86 */
+int grx_filter(grx_context_t ctx, grx_graph_t g, int32_t algorithm, int32_t vertex_op,
+               void* d_state, int32_t iparam, const int32_t* d_input, int64_t n_input,
+               int32_t* d_output, int64_t output_capacity, int64_t* n_output);
+/* operators::uniquify::execute<alg>(input, output, context, best_effort)  uniquify.hxx:15-42.
+ * GRX_UNIQUE leaves the result in d_input (d_output is scratch of >= n_input elements). */
+int grx_uniquify(grx_context_t ctx, int32_t algorithm, int32_t best_effort, int32_t* d_input,
+                 int64_t n_input, int32_t* d_output, int64_t output_capacity, int64_t* n_output);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
+/* The reference declares multi_context_t for several devices but every operator throws for
+ * size() != 1 (advance.hxx:125-128); this is new functionality. */
+#define GRX_UNIQUE_ID_BYTES 128
+int grx_comm_unique_id(void* h_id /* GRX_UNIQUE_ID_BYTES, rank 0 only; broadcast by the host */);
+int grx_comm_attach(grx_context_t ctx, const void* h_id, int rank, int world_size);
+int grx_comm_detach(grx_context_t ctx);
+/* Rows [row_begin,row_end) of the R-MAT graph as a rank-local CSR with GLOBAL column ids;
+ * split points balance edges (prefix of the global row offsets). */
+int grx_graph_rmat_partition(grx_context_t ctx, uint32_t scale, uint32_t edge_factor,
+                             uint64_t seed, uint64_t weight_seed, int symmetrize,
+                             grx_graph_t* out, int32_t* row_begin, int32_t* row_end);
+/* Rank-local slice of an existing (replicated) graph: same contract as above. */
+int grx_graph_partition(grx_context_t ctx, grx_graph_t full, grx_graph_t* out,
+                        int32_t* row_begin, int32_t* row_end);
+/* Vertex-partitioned BFS / SSSP: local advance over owned frontier vertices, RCCL
+ * all-gather of the per-rank output frontiers between BSP supersteps, min-combine into
+ * every rank's replica of the label array.  d_distances: [n_rows of the FULL graph]. */
+int grx_bfs_partitioned(grx_context_t ctx, grx_graph_t local, int32_t n_global,
+                        int32_t row_begin, int32_t row_end, int32_t source, int32_t* d_distances,
+                        const grx_options* opt, grx_stats* stats);
+int grx_sssp_partitioned(grx_context_t ctx, grx_graph_t local, int32_t n_global,
+                         int32_t row_begin, int32_t row_end, int32_t source, float* d_distances,
+                         const grx_options* opt, grx_stats* stats);
+
+/* ---- measurement helpers ------------------------------------------------- */
+/* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:
+ * the achievable-HBM roof quoted beside the 8 TB/s vendor peak. Returns GB/s. */
+int grx_measure_copy_bandwidth(grx_context_t ctx, size_t bytes, int repeats, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESSENTIALS_AMD_H */

@@ -1,0 +1,608 @@
+/**
+ * @file advance.hxx
+ * @brief operators::advance::execute -- neighbour expansion of a frontier.
+ *
+ * API of reference framework/operators/advance/advance.hxx:91-129 (frontier
+ * overload) and :192-221 (enactor overload): template arguments <load balance,
+ * direction, input type, output type>, functor bool(src, dst, edge, weight),
+ * buffers swapped afterwards unless output_type == none or swap_buffers == false.
+ * Unsupported combinations throw error::exception_t, like the reference.
+ *
+ * Host-side structure (per call, all on the context's stream):
+ *   1. clear the device counters (one 64-byte memset);
+ *   2. size the output: skipped when n_in * max_degree(G) already fits the output
+ *      frontier; otherwise one degree-sum kernel + a pinned read-back (the
+ *      reference does this reduction on EVERY call: advance/helpers.hxx:112-146);
+ *   3. the expansion kernel(s) of the chosen schedule;
+ *   4. ONE 8-byte read-back of the packed length + stream synchronise (operators
+ *      are synchronous, like block_mapped.hxx:204).
+ * No allocation happens in the steady state (the reference allocates a device
+ * cursor per call, block_mapped.hxx:200).
+ */
+#pragma once
+
+#include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/hip/context.hxx>
+#include <gunrock/hip/kernels/advance_kernels.hxx>
+#include <gunrock/hip/primitives.hxx>
+
+/// Compile-time override of the schedule hard-coded by a client header, e.g.
+/// -DGRX_ADVANCE_LB_OVERRIDE=bucketing to run the unchanged sssp.hxx (which
+/// spells block_mapped, algorithms/sssp.hxx:139) with degree bucketing.
+#ifdef GRX_ADVANCE_LB_OVERRIDE
+#define GRX_LB_EFFECTIVE(lb) (::gunrock::operators::load_balance_t::GRX_ADVANCE_LB_OVERRIDE)
+#else
+#define GRX_LB_EFFECTIVE(lb) (lb)
+#endif
+
+namespace gunrock {
+namespace operators {
+namespace advance {
+
+namespace detail {
+
+namespace k = ::gunrock::hip::kernels;
+
+inline unsigned grid_for(std::size_t items, std::size_t per_block, unsigned cap = 0x7fffffffu) {
+  std::size_t g = (items + per_block - 1) / per_block;
+  if (g < 1)
+    g = 1;
+  return (unsigned)(g > cap ? cap : g);
+}
+
+inline void clear_counters(gcuda::standard_context_t& ctx) {
+  GRX_HIP_CHECK(hipMemsetAsync(ctx.workspace().counters(), 0, 12 * sizeof(unsigned long long),
+                               ctx.stream()));
+}
+
+/// Copy the first 16 counters to the pinned mirror and wait for the stream.
+inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
+  auto& ws = ctx.workspace();
+  GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), ws.counters(), 16 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, ctx.stream()));
+  ctx.synchronize();
+  return ws.mirror();
+}
+
+struct clocked_t {
+  gcuda::standard_context_t& ctx;
+  explicit clocked_t(gcuda::standard_context_t& c) : ctx(c) {
+    if (ctx.options().time_kernels)
+      ctx.kernel_clock().start(ctx.stream());
+  }
+  void stop() {
+    if (ctx.options().time_kernels)
+      ctx.kernel_clock().stop(ctx.stream());
+  }
+};
+
+template <typename graph_t>
+unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
+  auto& ws = ctx.workspace();
+  const void* key = (const void*)G.get_row_offsets();
+  const std::size_t n = (std::size_t)G.get_number_of_vertices();
+  if (auto* f = ws.find_graph(key, n))
+    return f->max_degree;
+  unsigned long long* counters = ws.counters();
+  GRX_HIP_CHECK(hipMemsetAsync(counters + k::C_MAXDEG, 0, sizeof(unsigned long long), ctx.stream()));
+  if (n) {
+    k::max_degree_kernel<<<grid_for(n, k::ADV_BLOCK, 4096), k::ADV_BLOCK, 0, ctx.stream()>>>(
+        G, counters);
+    GRX_HIP_CHECK(hipGetLastError());
+  }
+  unsigned long long md = fetch_counters(ctx)[k::C_MAXDEG];
+  gcuda::workspace_t::graph_facts_t facts{key, n, md};
+  return ws.remember_graph(facts)->max_degree;
+}
+
+/// Sum of degrees of the valid input slots (64-bit).
+template <advance_io_type_t input_type, typename graph_t, typename vertex_t>
+unsigned long long degree_sum(graph_t& G, const vertex_t* input, std::size_t n_in,
+                              gcuda::standard_context_t& ctx) {
+  if (input_type == advance_io_type_t::graph)
+    return (unsigned long long)G.get_number_of_edges();
+  k::degree_sum_kernel<input_type><<<grid_for(n_in, k::ADV_BLOCK, 4096), k::ADV_BLOCK, 0,
+                                     ctx.stream()>>>(G, input, n_in, ctx.workspace().counters());
+  GRX_HIP_CHECK(hipGetLastError());
+  return fetch_counters(ctx)[k::C_WORK];
+}
+
+inline unsigned long long saturating_mul(unsigned long long a, unsigned long long b) {
+  if (a == 0 || b == 0)
+    return 0;
+  if (a > ~0ull / b)
+    return ~0ull;
+  return a * b;
+}
+
+/**
+ * @brief Make sure `output` can take the result.  Returns false when the
+ * operator has nothing to do (no work), with the output already set empty.
+ * `total` receives the exact work size when it had to be computed (else ~0).
+ */
+template <advance_io_type_t input_type, typename graph_t, typename frontier_t>
+bool size_output(graph_t& G, frontier_t& input, frontier_t& output, std::size_t n_in, bool exact,
+                 unsigned long long& total, gcuda::standard_context_t& ctx) {
+  total = ~0ull;
+  const unsigned long long bound = saturating_mul(n_in, max_degree(G, ctx));
+  if (!exact && bound <= output.get_capacity())
+    return true;
+  total = degree_sum<input_type>(G, input.data(), n_in, ctx);
+  if (total == 0) {
+    output.set_number_of_elements(0);
+    return false;
+  }
+  if (output.get_capacity() < total)
+    output.reserve(total);
+  return true;
+}
+
+template <typename frontier_t>
+void finish_output(frontier_t& output, bool holes, unsigned long long total,
+                   gcuda::standard_context_t& ctx) {
+  unsigned long long* m = fetch_counters(ctx);
+  ctx.kernel_clock().collect();
+  error::throw_if_exception(m[k::C_OVERFLOW] != 0,
+                            "advance: output frontier capacity exceeded");
+  output.set_number_of_elements(holes ? (std::size_t)total : (std::size_t)m[k::C_OUT]);
+}
+
+/// Device chunk queue sized for every hub of the graph at once.
+template <typename vertex_t, typename edge_t, typename graph_t>
+k::chunk_t<vertex_t, edge_t>* chunk_queue(graph_t& G, unsigned long long& capacity,
+                                          gcuda::standard_context_t& ctx) {
+  capacity = (unsigned long long)G.get_number_of_edges() / k::ADV_CHUNK + 65536;
+  return reinterpret_cast<k::chunk_t<vertex_t, edge_t>*>(
+      ctx.workspace().queue(capacity * sizeof(k::chunk_t<vertex_t, edge_t>)));
+}
+
+}  // namespace detail
+
+// ===========================================================================
+// block_mapped (and work_stealing = the same kernel with dynamic tile claims)
+// ===========================================================================
+namespace block_mapped {
+
+template <advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          bool dynamic_tiles = false,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+
+  const std::size_t n_in = (input_type == advance_io_type_t::graph)
+                               ? (std::size_t)G.get_number_of_vertices()
+                               : input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  const bool holes = has_out && context.options().holes_layout;
+  const unsigned long long max_deg = detail::max_degree(G, context);
+  detail::clear_counters(context);
+  unsigned long long total = ~0ull;
+  if (has_out) {
+    if (!detail::size_output<input_type>(G, input, output, n_in, holes, total, context))
+      return;
+  }
+
+  unsigned long long chunk_capacity = 0;
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, chunk_capacity, context);
+  const unsigned hub_threshold = context.options().hub_threshold;
+  unsigned long long* counters = context.workspace().counters();
+  const std::size_t n_tiles = (n_in + k::ADV_BLOCK - 1) / k::ADV_BLOCK;
+  const unsigned persistent = (unsigned)context.compute_units() * 8u;
+  const unsigned grid = dynamic_tiles ? (unsigned)(n_tiles < persistent ? n_tiles : persistent)
+                                      : detail::grid_for(n_tiles, 1);
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+
+  detail::clocked_t clock(context);
+  if (holes) {
+    k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>
+        <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
+                                                      counters, chunks, chunk_capacity,
+                                                      hub_threshold);
+  } else {
+    k::block_mapped_kernel<false, dynamic_tiles, input_type, output_type>
+        <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
+                                                      counters, chunks, chunk_capacity,
+                                                      hub_threshold);
+    if (max_deg >= hub_threshold) {
+      k::chunk_kernel<output_type><<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0,
+                                     context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr,
+                                                         capacity, counters);
+    }
+  }
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, holes, total, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace block_mapped
+
+// ===========================================================================
+// merge_path: device-wide degree scan + equal shares of edges
+// ===========================================================================
+namespace merge_path {
+
+/// segments[0..n_in] = exclusive scan of the input slots' degrees; returns the total.
+/// (reference advance/helpers.hxx:38-96, compute_output_offsets)
+template <advance_io_type_t input_type, typename graph_t, typename vertex_t, typename work_tiles_t>
+unsigned long long scan_degrees(graph_t& G, const vertex_t* input, std::size_t n_in,
+                                work_tiles_t& segments, gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using edge_t = typename graph_t::edge_type;
+  if (segments.size() < n_in + 1)
+    segments.resize(n_in + 1);
+  edge_t* seg = segments.data();
+  k::slot_degree_kernel<input_type><<<detail::grid_for(n_in + 1, k::ADV_BLOCK, 4096),
+                                      k::ADV_BLOCK, 0, context.stream()>>>(G, input, n_in, seg);
+  GRX_HIP_CHECK(hipGetLastError());
+  std::size_t bytes = hip::exclusive_sum_temp_bytes(seg, seg, edge_t(0), n_in + 1);
+  void* temp = context.workspace().scratch(bytes);
+  hip::exclusive_sum(temp, bytes, seg, seg, edge_t(0), n_in + 1, context.stream());
+  auto& ws = context.workspace();
+  edge_t* landing = reinterpret_cast<edge_t*>(ws.mirror() + 24);
+  GRX_HIP_CHECK(hipMemcpyAsync(landing, seg + n_in, sizeof(edge_t), hipMemcpyDeviceToHost,
+                               context.stream()));
+  context.synchronize();
+  return (unsigned long long)*landing;
+}
+
+template <advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t,
+          typename work_tiles_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             work_tiles_t& segments,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+  const std::size_t n_in = (input_type == advance_io_type_t::graph)
+                               ? (std::size_t)G.get_number_of_vertices()
+                               : input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  const bool holes = has_out && context.options().holes_layout;
+  detail::clear_counters(context);
+  const unsigned long long total = scan_degrees<input_type>(G, input.data(), n_in, segments, context);
+  if (total == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  if (has_out && output.get_capacity() < total)
+    output.reserve(total);
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+  const unsigned grid = detail::grid_for(total, k::MP_TILE);
+  unsigned long long* counters = context.workspace().counters();
+  detail::clocked_t clock(context);
+  if (holes)
+    k::merge_path_kernel<true, input_type, output_type><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, input.data(), n_in, segments.data(), total, out_ptr, capacity, counters);
+  else
+    k::merge_path_kernel<false, input_type, output_type><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, input.data(), n_in, segments.data(), total, out_ptr, capacity, counters);
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, holes, total, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace merge_path
+
+// ===========================================================================
+// thread_mapped / warp_mapped
+// ===========================================================================
+namespace thread_mapped {
+
+template <advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t,
+          typename work_tiles_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             work_tiles_t& segments,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+  const std::size_t n_in = (input_type == advance_io_type_t::graph)
+                               ? (std::size_t)G.get_number_of_vertices()
+                               : input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  const bool holes = has_out && context.options().holes_layout;
+  detail::clear_counters(context);
+  unsigned long long total = ~0ull;
+  const edge_t* seg = nullptr;
+  if (holes) {
+    total = merge_path::scan_degrees<input_type>(G, input.data(), n_in, segments, context);
+    if (total == 0) {
+      output.set_number_of_elements(0);
+      return;
+    }
+    if (output.get_capacity() < total)
+      output.reserve(total);
+    seg = segments.data();
+  } else if (has_out) {
+    if (!detail::size_output<input_type>(G, input, output, n_in, false, total, context))
+      return;
+  }
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+  const unsigned grid = detail::grid_for(n_in, k::ADV_BLOCK);
+  unsigned long long* counters = context.workspace().counters();
+  detail::clocked_t clock(context);
+  if (holes)
+    k::thread_mapped_kernel<true, input_type, output_type>
+        <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, seg, out_ptr,
+                                                      capacity, counters);
+  else
+    k::thread_mapped_kernel<false, input_type, output_type>
+        <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, seg, out_ptr,
+                                                      capacity, counters);
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, holes, total, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace thread_mapped
+
+namespace warp_mapped {
+
+template <advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+  const std::size_t n_in = (input_type == advance_io_type_t::graph)
+                               ? (std::size_t)G.get_number_of_vertices()
+                               : input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  detail::clear_counters(context);
+  unsigned long long total = ~0ull;
+  if (has_out) {
+    if (!detail::size_output<input_type>(G, input, output, n_in, false, total, context))
+      return;
+  }
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+  const unsigned grid = detail::grid_for(n_in, k::ADV_WAVES * 16);
+  detail::clocked_t clock(context);
+  k::wave_mapped_kernel<input_type, output_type><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
+      G, op, input.data(), n_in, out_ptr, capacity, context.workspace().counters());
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, false, total, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace warp_mapped
+
+// ===========================================================================
+// bucketing: thread / wavefront / chunk schedules by degree class
+// ===========================================================================
+namespace bucketing {
+
+template <advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+  constexpr advance_io_type_t vin = advance_io_type_t::vertices;
+  const std::size_t n_in = (input_type == advance_io_type_t::graph)
+                               ? (std::size_t)G.get_number_of_vertices()
+                               : input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  detail::clear_counters(context);
+  unsigned long long total = ~0ull;
+  if (has_out) {
+    if (!detail::size_output<input_type>(G, input, output, n_in, false, total, context))
+      return;
+  }
+  auto& ws = context.workspace();
+  unsigned long long chunk_capacity = 0;
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, chunk_capacity, context);
+  vertex_t* bins = reinterpret_cast<vertex_t*>(ws.scratch(2 * n_in * sizeof(vertex_t)));
+  vertex_t* small_q = bins;
+  vertex_t* medium_q = bins + n_in;
+  unsigned long long* counters = ws.counters();
+  const unsigned hub_threshold = context.options().hub_threshold;
+
+  detail::clocked_t clock(context);
+  k::bucket_kernel<input_type><<<detail::grid_for(n_in, k::ADV_BLOCK, (unsigned)context.compute_units() * 8u),
+                                 k::ADV_BLOCK, 0, context.stream()>>>(
+      G, input.data(), n_in, small_q, medium_q, chunks, chunk_capacity, hub_threshold, counters);
+  GRX_HIP_CHECK(hipGetLastError());
+  unsigned long long* m = detail::fetch_counters(context);
+  const std::size_t n_small = (std::size_t)m[k::C_BUCKET0];
+  const std::size_t n_medium = (std::size_t)m[k::C_BUCKET0 + 1];
+  const unsigned long long n_chunks = m[k::C_CHUNKS];
+
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+  if (n_small)
+    k::thread_mapped_kernel<false, vin, output_type>
+        <<<detail::grid_for(n_small, k::ADV_BLOCK), k::ADV_BLOCK, 0, context.stream()>>>(
+            G, op, small_q, n_small, (const edge_t*)nullptr, out_ptr, capacity, counters);
+  if (n_medium)
+    k::wave_mapped_kernel<vin, output_type>
+        <<<detail::grid_for(n_medium, k::ADV_WAVES * 16), k::ADV_BLOCK, 0, context.stream()>>>(
+            G, op, medium_q, n_medium, out_ptr, capacity, counters);
+  if (n_chunks)
+    k::chunk_kernel<output_type>
+        <<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0, context.stream()>>>(
+            G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, false, total, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace bucketing
+
+// ===========================================================================
+// dispatch
+// ===========================================================================
+
+/**
+ * @brief Frontier-level entry (reference advance.hxx:91-129).
+ */
+template <load_balance_t lb,
+          advance_direction_t direction,
+          advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t,
+          typename work_tiles_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t* input,
+             frontier_t* output,
+             work_tiles_t& segments,
+             gcuda::multi_context_t& context) {
+  error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
+  error::throw_if_exception(direction != advance_direction_t::forward,
+                            "advance: only the forward (push) direction is implemented");
+  error::throw_if_exception(input_type == advance_io_type_t::edges ||
+                                output_type == advance_io_type_t::edges ||
+                                output_type == advance_io_type_t::graph,
+                            "Advance type not supported.");
+  auto& ctx = *context.get_context(0);
+  constexpr load_balance_t schedule = GRX_LB_EFFECTIVE(lb);
+  // deterministic output positions exist only for merge_path / thread_mapped / block_mapped
+  const bool holes = ctx.options().holes_layout && output_type != advance_io_type_t::none;
+
+  if constexpr (schedule == load_balance_t::block_mapped) {
+    block_mapped::execute<direction, input_type, output_type, false>(G, op, *input, *output, ctx);
+  } else if constexpr (schedule == load_balance_t::work_stealing) {
+    block_mapped::execute<direction, input_type, output_type, true>(G, op, *input, *output, ctx);
+  } else if constexpr (schedule == load_balance_t::merge_path ||
+                       schedule == load_balance_t::merge_path_v2) {
+    merge_path::execute<direction, input_type, output_type>(G, op, *input, *output, segments, ctx);
+  } else if constexpr (schedule == load_balance_t::thread_mapped) {
+    thread_mapped::execute<direction, input_type, output_type>(G, op, *input, *output, segments, ctx);
+  } else if constexpr (schedule == load_balance_t::warp_mapped) {
+    if (holes)
+      merge_path::execute<direction, input_type, output_type>(G, op, *input, *output, segments, ctx);
+    else
+      warp_mapped::execute<direction, input_type, output_type>(G, op, *input, *output, ctx);
+  } else if constexpr (schedule == load_balance_t::bucketing) {
+    if (holes)
+      merge_path::execute<direction, input_type, output_type>(G, op, *input, *output, segments, ctx);
+    else
+      bucketing::execute<direction, input_type, output_type>(G, op, *input, *output, ctx);
+  } else {
+    error::throw_if_exception(true, "Advance type not supported.");
+  }
+}
+
+/**
+ * @brief Enactor-level entry (reference advance.hxx:192-221): uses the enactor's
+ * input/output frontiers and scan workspace, then swaps the buffers.
+ */
+template <load_balance_t lb = load_balance_t::merge_path,
+          advance_direction_t direction = advance_direction_t::forward,
+          advance_io_type_t input_type = advance_io_type_t::vertices,
+          advance_io_type_t output_type = advance_io_type_t::vertices,
+          typename graph_t,
+          typename enactor_type,
+          typename operator_type>
+void execute(graph_t& G,
+             enactor_type* E,
+             operator_type op,
+             gcuda::multi_context_t& context,
+             bool swap_buffers = true) {
+  execute<lb, direction, input_type, output_type>(G, op, E->get_input_frontier(),
+                                                  E->get_output_frontier(),
+                                                  E->scanned_work_domain, context);
+  if (swap_buffers && (output_type != advance_io_type_t::none))
+    E->swap_frontier_buffers();
+}
+
+}  // namespace advance
+}  // namespace operators
+}  // namespace gunrock

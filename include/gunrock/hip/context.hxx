@@ -1,0 +1,328 @@
+/**
+ * @file context.hxx
+ * @brief Device context of the engine: one HIP stream + event timer + a
+ * persistent operator workspace per GPU.
+ *
+ * Replaces reference include/gunrock/cuda/context.hxx:54-206 (standard_context_t,
+ * multi_context_t) and include/gunrock/util/timer.hxx:16-49.  The namespace keeps
+ * the name `gcuda` because the client headers spell it (algorithms/bfs.hxx:44,156).
+ *
+ * MI355X-first differences:
+ *  - the context owns a workspace (device counters, pinned mirror, scratch) so an
+ *    operator call performs no hipMalloc/hipFree (the reference allocates a
+ *    1-element device_vector per advance: advance/block_mapped.hxx:200);
+ *  - the timer records on the context's stream (the reference records on the
+ *    null stream while work runs on a non-blocking stream);
+ *  - multi-GPU is one process per GPU: a multi_context_t holds the local device's
+ *    context plus {rank, world_size, communicator} of the RCCL job (the reference
+ *    only holds a vector of local contexts and never uses more than the first:
+ *    framework/enactor.hxx:243-254).
+ */
+#pragma once
+
+#include <gunrock/hip/runtime.hxx>
+
+#include <cstdio>
+
+#include <thrust/execution_policy.h>
+#include <thrust/system/hip/execution_policy.h>
+
+namespace gunrock {
+
+namespace util {
+
+/// Event-pair timer on a stream; enact() returns its milliseconds.
+struct timer_t {
+  float time = 0.0f;
+
+  explicit timer_t(hipStream_t stream = nullptr) : stream_(stream) {
+    GRX_HIP_CHECK(hipEventCreate(&start_));
+    GRX_HIP_CHECK(hipEventCreate(&stop_));
+  }
+  timer_t(const timer_t&) = delete;
+  timer_t& operator=(const timer_t&) = delete;
+  ~timer_t() {
+    (void)hipEventDestroy(start_);
+    (void)hipEventDestroy(stop_);
+  }
+
+  void begin() { GRX_HIP_CHECK(hipEventRecord(start_, stream_)); }
+  void start() { begin(); }
+  float end() {
+    GRX_HIP_CHECK(hipEventRecord(stop_, stream_));
+    GRX_HIP_CHECK(hipEventSynchronize(stop_));
+    GRX_HIP_CHECK(hipEventElapsedTime(&time, start_, stop_));
+    return time;
+  }
+  float stop() { return end(); }
+  float seconds() const { return time * 1e-3f; }
+  float milliseconds() const { return time; }
+  void set_stream(hipStream_t s) { stream_ = s; }
+
+ private:
+  hipEvent_t start_{}, stop_{};
+  hipStream_t stream_ = nullptr;
+};
+
+}  // namespace util
+
+namespace gcuda {
+
+using device_id_t = int;
+using stream_t = hipStream_t;
+using event_t = hipEvent_t;
+
+/// Hardware constants of the one target (MI355X / gfx950, CDNA4).
+struct gfx950 {
+  static constexpr int wavefront_size = 64;
+  static constexpr int compute_units = 256;
+  static constexpr int xcds = 8;
+  static constexpr int lds_bytes_per_cu = 160 * 1024;
+};
+
+/**
+ * @brief Per-context operator workspace.  All operator state lives here (no
+ * globals) so that independent contexts on independent host threads do not
+ * interfere (reference operators::batch runs N run() calls on N threads).
+ */
+class workspace_t {
+ public:
+  static constexpr std::size_t n_counters = 32;
+
+  /// 64-bit device counters (output cursor, hub-queue cursor, tile cursor, ...).
+  unsigned long long* counters() {
+    if (!counters_.data()) {
+      counters_.reserve(n_counters);
+      GRX_HIP_CHECK(hipMemset(counters_.data(), 0, n_counters * sizeof(unsigned long long)));
+    }
+    return counters_.data();
+  }
+  /// Pinned host mirror of the counters.
+  unsigned long long* mirror() { return mirror_.data(); }
+
+  /// Growable untyped scratch (rocPRIM temp storage, block counts, flag words).
+  void* scratch(std::size_t bytes) {
+    if (bytes > scratch_.capacity())
+      scratch_.reserve(bytes + bytes / 4);
+    return scratch_.data();
+  }
+  /// A second, independent scratch region (e.g. the hub chunk queue).
+  void* queue(std::size_t bytes) {
+    if (bytes > queue_.capacity())
+      queue_.reserve(bytes);
+    return queue_.data();
+  }
+  std::size_t queue_capacity_bytes() const { return queue_.capacity(); }
+
+  /// Per-graph facts an operator needs on the host (keyed by the offsets pointer).
+  struct graph_facts_t {
+    const void* key = nullptr;
+    std::size_t vertices = 0;
+    unsigned long long max_degree = 0;
+  };
+  graph_facts_t* find_graph(const void* key, std::size_t vertices) {
+    for (auto& g : graphs_)
+      if (g.key == key && g.vertices == vertices)
+        return &g;
+    return nullptr;
+  }
+  graph_facts_t* remember_graph(const graph_facts_t& g) {
+    graphs_.push_back(g);
+    return &graphs_.back();
+  }
+
+ private:
+  hip::buffer_t<unsigned long long> counters_;
+  hip::pinned_t<unsigned long long> mirror_{n_counters};
+  hip::buffer_t<unsigned char> scratch_;
+  hip::buffer_t<unsigned char> queue_;
+  std::vector<graph_facts_t> graphs_;
+};
+
+/// Run-time switches of the operators (per context).
+struct operator_options_t {
+  /// true: advance writes one output slot per traversed edge, invalid where the
+  /// functor said no (the reference's layout, advance/block_mapped.hxx:142-145);
+  /// false (default): only accepted neighbours are written, packed.
+  bool holes_layout = false;
+  /// Neighbour lists at least this long are cut into chunks spread over the GPU.
+  unsigned hub_threshold = 2048;
+  /// Event-time the advance expansion kernels (two events per operator call).
+  bool time_kernels = false;
+};
+
+/// Accumulated device time of the advance expansion kernels (when enabled).
+struct kernel_clock_t {
+  float total_ms = 0.0f;
+  int launches = 0;
+  bool pending = false;
+  hipEvent_t begin_{}, end_{};
+  bool created = false;
+  void ensure() {
+    if (!created) {
+      GRX_HIP_CHECK(hipEventCreate(&begin_));
+      GRX_HIP_CHECK(hipEventCreate(&end_));
+      created = true;
+    }
+  }
+  void start(hipStream_t s) {
+    ensure();
+    GRX_HIP_CHECK(hipEventRecord(begin_, s));
+  }
+  void stop(hipStream_t s) {
+    GRX_HIP_CHECK(hipEventRecord(end_, s));
+    pending = true;
+  }
+  /// Call after the stream has been synchronised.
+  void collect() {
+    if (!pending)
+      return;
+    float ms = 0;
+    GRX_HIP_CHECK(hipEventSynchronize(end_));
+    GRX_HIP_CHECK(hipEventElapsedTime(&ms, begin_, end_));
+    total_ms += ms;
+    ++launches;
+    pending = false;
+  }
+  void reset() { total_ms = 0; launches = 0; pending = false; }
+  ~kernel_clock_t() {
+    if (created) {
+      (void)hipEventDestroy(begin_);
+      (void)hipEventDestroy(end_);
+    }
+  }
+};
+
+class standard_context_t {
+ public:
+  explicit standard_context_t(device_id_t device = 0) : ordinal_(device), owns_stream_(true) {
+    GRX_HIP_CHECK(hipSetDevice(ordinal_));
+    GRX_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    init();
+  }
+  standard_context_t(stream_t stream, device_id_t device = 0)
+      : ordinal_(device), stream_(stream), owns_stream_(false) {
+    GRX_HIP_CHECK(hipSetDevice(ordinal_));
+    init();
+  }
+  standard_context_t(const standard_context_t&) = delete;
+  standard_context_t& operator=(const standard_context_t&) = delete;
+  ~standard_context_t() {
+    timer_.reset();
+    (void)hipEventDestroy(event_);
+    if (owns_stream_)
+      (void)hipStreamDestroy(stream_);
+  }
+
+  stream_t stream() { return stream_; }
+  event_t event() { return event_; }
+  device_id_t ordinal() const { return ordinal_; }
+  util::timer_t& timer() { return *timer_; }
+  workspace_t& workspace() { return workspace_; }
+  operator_options_t& options() { return options_; }
+  kernel_clock_t& kernel_clock() { return clock_; }
+  const hipDeviceProp_t& props() const { return props_; }
+  int compute_units() const { return props_.multiProcessorCount; }
+
+  void synchronize() {
+    GRX_HIP_CHECK(stream_ ? hipStreamSynchronize(stream_) : hipDeviceSynchronize());
+  }
+
+  /// Policy for the clients' own thrust calls (sssp.hxx:57, pr.hxx:66); the
+  /// engine's operators do not use thrust.
+  auto execution_policy() { return thrust::hip::par_nosync.on(stream_); }
+
+  void print_properties() const {
+    std::printf("%s: %d CUs, wavefront %d, %zu MiB L2, %.1f GiB\n", props_.name,
+                props_.multiProcessorCount, props_.warpSize,
+                (std::size_t)props_.l2CacheSize >> 20,
+                (double)props_.totalGlobalMem / (1ull << 30));
+  }
+
+ private:
+  void init() {
+    GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));
+    GRX_HIP_CHECK(hipGetDeviceProperties(&props_, ordinal_));
+    timer_ = std::make_unique<util::timer_t>(stream_);
+  }
+
+  device_id_t ordinal_ = 0;
+  stream_t stream_ = nullptr;
+  bool owns_stream_ = false;
+  event_t event_{};
+  hipDeviceProp_t props_{};
+  std::unique_ptr<util::timer_t> timer_;
+  workspace_t workspace_;
+  operator_options_t options_;
+  kernel_clock_t clock_;
+};
+
+/**
+ * @brief The context handed to problem_t / enactor_t / operators.  size() is the
+ * number of LOCAL device contexts (1 in the process-per-GPU model); world_size()
+ * is the number of ranks of the job the context is attached to.
+ */
+class multi_context_t {
+ public:
+  static constexpr std::size_t MAX_NUMBER_OF_GPUS = 1024;
+
+  std::vector<standard_context_t*> contexts;
+  std::vector<device_id_t> devices;
+
+  explicit multi_context_t(device_id_t device) : devices(1, device) {
+    contexts.push_back(new standard_context_t(device));
+  }
+  multi_context_t(device_id_t device, stream_t stream) : devices(1, device) {
+    contexts.push_back(new standard_context_t(stream, device));
+  }
+  explicit multi_context_t(std::vector<device_id_t> _devices) : devices(std::move(_devices)) {
+    for (auto d : devices)
+      contexts.push_back(new standard_context_t(d));
+    if (!devices.empty())
+      GRX_HIP_CHECK(hipSetDevice(devices[0]));
+  }
+  multi_context_t(const multi_context_t&) = delete;
+  multi_context_t& operator=(const multi_context_t&) = delete;
+  ~multi_context_t() {
+    for (auto* c : contexts)
+      delete c;
+  }
+
+  standard_context_t* get_context(device_id_t i) { return contexts[(std::size_t)i]; }
+  std::size_t size() const { return contexts.size(); }
+
+  /// Peer access between the local devices (reference cuda/context.hxx:188-205).
+  void enable_peer_access() {
+    int n = (int)size();
+    for (int i = 0; i < n; ++i) {
+      GRX_HIP_CHECK(hipSetDevice(contexts[i]->ordinal()));
+      for (int j = 0; j < n; ++j) {
+        if (i == j)
+          continue;
+        hipError_t st = hipDeviceEnablePeerAccess(contexts[j]->ordinal(), 0);
+        if (st != hipSuccess && st != hipErrorPeerAccessAlreadyEnabled)
+          error::throw_if_exception(st, "hipDeviceEnablePeerAccess");
+      }
+    }
+    if (n)
+      GRX_HIP_CHECK(hipSetDevice(contexts[0]->ordinal()));
+  }
+
+  // --- process-per-GPU job attachment (RCCL over xGMI) ----------------------
+  void attach_job(int rank, int world_size, void* communicator) {
+    rank_ = rank;
+    world_ = world_size;
+    comm_ = communicator;
+  }
+  int rank() const { return rank_; }
+  int world_size() const { return world_; }
+  void* communicator() const { return comm_; }
+
+ private:
+  int rank_ = 0;
+  int world_ = 1;
+  void* comm_ = nullptr;  // ncclComm_t, owned by whoever attached it
+};
+
+}  // namespace gcuda
+}  // namespace gunrock

@@ -1,0 +1,728 @@
+/**
+ * @file advance_kernels.hxx
+ * @brief Hand-written gfx950 kernels of the advance operator: neighbour-list
+ * expansion of a frontier over CSR with an opaque per-edge functor.
+ *
+ * The contract is the reference's (framework/operators/advance/block_mapped.hxx:
+ * 30-147, thread_mapped.hxx:25-96, merge_path.hxx:28-114): for every VALID input
+ * slot and every out-edge e=(v,n) call op(v, n, e, w) exactly once; when an output
+ * frontier is requested, emit n where op returned true.  Everything else --
+ * schedules, LDS staging, output packing -- is designed for CDNA4:
+ *
+ *  - 256-thread workgroups = 4 wavefronts of 64 lanes; a lane reads
+ *    column_indices[e] for CONSECUTIVE e across the wavefront (coalesced 256-B
+ *    requests out of HBM), never a private list unless the schedule is
+ *    thread_mapped;
+ *  - the per-tile (vertex, first edge, scanned degree) triples live in LDS and
+ *    the owner of edge i is found by binary search there;
+ *  - accepted neighbours are packed with ballot + mbcnt into a PER-WAVEFRONT LDS
+ *    queue whose fill level is a wave-uniform register: no LDS atomics, no
+ *    workgroup barrier while expanding; a workgroup issues ONE global cursor
+ *    atomic per tile (queues are drained together), so the single output cursor
+ *    sees O(tiles) atomics instead of O(edges/64);
+ *  - lists of >= hub_threshold edges are not expanded in place: they are cut into
+ *    fixed chunks appended to a device queue that a second, persistent kernel
+ *    spreads over all 256 CUs (an RMAT-22 hub has 3e5 edges);
+ *  - "holes" layout (one output slot per traversed edge, invalid where the op
+ *    said no) reproduces the reference's output exactly and is kept as a mode;
+ *    the default "packed" layout writes only accepted neighbours.
+ *
+ * Counter slots of workspace_t::counters() used here: see counter_slot.
+ */
+#pragma once
+
+#include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/hip/primitives.hxx>
+#include <gunrock/util/type_limits.hxx>
+
+namespace gunrock {
+namespace hip {
+namespace kernels {
+
+using operators::advance_io_type_t;
+
+constexpr int ADV_BLOCK = 256;                        // threads per workgroup
+constexpr int ADV_WAVES = ADV_BLOCK / wave_size;      // 4
+constexpr int ADV_WQCAP = 512;                        // entries of one wavefront's output queue
+constexpr int ADV_UNROLL = 4;                         // independent edges in flight per lane
+constexpr int ADV_CHUNK = 2048;                       // edges per hub chunk
+constexpr int ADV_HUB_THRESHOLD = ADV_CHUNK;          // lists this long are chunked
+
+enum counter_slot : int {
+  C_OUT = 0,        ///< output cursor (elements)
+  C_CHUNKS = 1,     ///< hub chunk queue cursor
+  C_WORK = 2,       ///< degree sum / total work of the input frontier
+  C_OVERFLOW = 3,   ///< set when an output write was dropped for lack of capacity
+  C_TILE = 4,       ///< dynamic tile cursor (work_stealing)
+  C_BUCKET0 = 8,    ///< bucketing: small / medium / large queue cursors (8,9,10)
+  C_MAXDEG = 12,    ///< max degree reduction
+  C_SELECT = 16     ///< compaction: number of selected elements
+};
+
+template <typename vertex_t, typename edge_t>
+struct chunk_t {
+  vertex_t source;
+  int count;
+  edge_t first;
+};
+
+
+/**
+ * @brief Cut a long neighbour list into ADV_CHUNK-edge descriptors appended to
+ * the device chunk queue.  Returns false (nothing usable written) when the queue
+ * cannot take the whole list; the part of the reservation that does fit is then
+ * filled with empty descriptors so the consumer never reads unwritten entries.
+ */
+template <typename vertex_t, typename edge_t>
+__device__ __forceinline__ bool spill_hub(vertex_t v, edge_t first, unsigned deg,
+                                          chunk_t<vertex_t, edge_t>* chunks,
+                                          unsigned long long chunk_capacity,
+                                          unsigned long long* counters) {
+  const unsigned n_chunks = (deg + ADV_CHUNK - 1) / ADV_CHUNK;
+  const unsigned long long at = atomicAdd(&counters[C_CHUNKS], (unsigned long long)n_chunks);
+  const bool fits = at + n_chunks <= chunk_capacity;
+  for (unsigned c = 0; c < n_chunks && at + c < chunk_capacity; ++c) {
+    const unsigned off = c * ADV_CHUNK;
+    chunk_t<vertex_t, edge_t> d;
+    d.source = v;
+    d.first = first + (edge_t)off;
+    d.count = fits ? (int)((deg - off < (unsigned)ADV_CHUNK) ? deg - off : (unsigned)ADV_CHUNK) : 0;
+    chunks[at + c] = d;
+  }
+  return fits;
+}
+
+// ---------------------------------------------------------------------------
+// Per-wavefront output queue (LDS), fill level in a wave-uniform register.
+// ---------------------------------------------------------------------------
+template <typename vertex_t>
+struct wave_queue_t {
+  vertex_t* q;     // this wavefront's ADV_WQCAP entries in LDS
+  unsigned fill;   // wave-uniform
+
+  __device__ __forceinline__ void flush(vertex_t* out, std::size_t capacity,
+                                        unsigned long long* counters) {
+    if (fill == 0)
+      return;
+    const int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0)
+      base = atomicAdd(&counters[C_OUT], (unsigned long long)fill);
+    base = __shfl(base, 0, wave_size);
+    for (unsigned j = lane; j < fill; j += wave_size) {
+      if (base + j < capacity)
+        out[base + j] = q[j];
+      else
+        counters[C_OVERFLOW] = 1ull;
+    }
+    fill = 0;
+  }
+
+  /// All 64 lanes must call (keep=false for idle lanes).
+  __device__ __forceinline__ void push(bool keep, vertex_t value, vertex_t* out,
+                                       std::size_t capacity, unsigned long long* counters) {
+    unsigned long long m = __ballot(keep);
+    if (m == 0)
+      return;
+    if (fill + wave_size > (unsigned)ADV_WQCAP)
+      flush(out, capacity, counters);
+    if (keep)
+      q[fill + rank_in_mask(m)] = value;
+    fill += (unsigned)__popcll(m);
+  }
+};
+
+/// Drain the four wavefront queues of a workgroup with ONE global atomic.
+template <typename vertex_t>
+__device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned* s_counts,
+                                            unsigned long long* s_base, vertex_t* out,
+                                            std::size_t capacity, unsigned long long* counters) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x / wave_size;
+  if (lane == 0)
+    s_counts[wave] = wq.fill;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+#pragma unroll
+    for (int w = 0; w < ADV_WAVES; ++w)
+      total += s_counts[w];
+    *s_base = total ? atomicAdd(&counters[C_OUT], (unsigned long long)total) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long base = *s_base;
+  for (int w = 0; w < wave; ++w)
+    base += s_counts[w];
+  for (unsigned j = lane; j < wq.fill; j += wave_size) {
+    if (base + j < capacity)
+      out[base + j] = wq.q[j];
+    else
+      counters[C_OVERFLOW] = 1ull;
+  }
+  wq.fill = 0;
+  __syncthreads();  // s_counts / s_base are reused by the next tile
+}
+
+// ---------------------------------------------------------------------------
+// Sum / max of degrees of the valid input slots.
+// Restates advance/helpers.hxx:112-146 (compute_output_length) as one kernel with
+// a 64-bit result (the reference sums in edge_t, SURVEY.md 8a' q8).
+// ---------------------------------------------------------------------------
+template <advance_io_type_t IN, typename graph_t, typename vertex_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    degree_sum_kernel(graph_t G, const vertex_t* input, std::size_t n_in,
+                      unsigned long long* counters) {
+  unsigned long long local = 0;
+  for (std::size_t i = blockIdx.x * (std::size_t)ADV_BLOCK + threadIdx.x; i < n_in;
+       i += (std::size_t)gridDim.x * ADV_BLOCK) {
+    vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)i : input[i];
+    if (util::limits::is_valid(v))
+      local += (unsigned long long)G.get_number_of_neighbors(v);
+  }
+  local = wave_sum(local);
+  if (lane_id() == 0 && local)
+    atomicAdd(&counters[C_WORK], local);
+}
+
+template <typename graph_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    max_degree_kernel(graph_t G, unsigned long long* counters) {
+  using vertex_t = typename graph_t::vertex_type;
+  unsigned long long local = 0;
+  const std::size_t n = (std::size_t)G.get_number_of_vertices();
+  for (std::size_t i = blockIdx.x * (std::size_t)ADV_BLOCK + threadIdx.x; i < n;
+       i += (std::size_t)gridDim.x * ADV_BLOCK) {
+    unsigned long long d = (unsigned long long)G.get_number_of_neighbors((vertex_t)i);
+    local = d > local ? d : local;
+  }
+  local = wave_max(local);
+  if (lane_id() == 0 && local)
+    atomicMax(&counters[C_MAXDEG], local);
+}
+
+// ---------------------------------------------------------------------------
+// block_mapped: one workgroup per tile of ADV_BLOCK input slots.
+// ---------------------------------------------------------------------------
+template <bool HOLES,
+          bool DYNAMIC,
+          advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t,
+          typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    block_mapped_kernel(graph_t G,
+                        op_t op,
+                        const vertex_t* __restrict__ input,
+                        std::size_t n_in,
+                        vertex_t* __restrict__ output,
+                        std::size_t capacity,
+                        unsigned long long* counters,
+                        chunk_t<vertex_t, edge_t>* chunks,
+                        unsigned long long chunk_capacity,
+                        unsigned hub_threshold) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+
+  __shared__ vertex_t s_vertex[ADV_BLOCK];
+  __shared__ edge_t s_first[ADV_BLOCK];
+  __shared__ unsigned s_scan[ADV_BLOCK];
+  __shared__ unsigned s_wave_totals[ADV_WAVES + 1];
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned long long s_tile;
+  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+
+  const int tid = threadIdx.x;
+  const int wave = tid / wave_size;
+  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? wave * ADV_WQCAP : 0), 0u};
+
+  const unsigned long long n_tiles = (n_in + ADV_BLOCK - 1) / ADV_BLOCK;
+  unsigned long long tile = blockIdx.x;
+  if (DYNAMIC) {
+    if (tid == 0)
+      s_tile = atomicAdd(&counters[C_TILE], 1ull);
+    __syncthreads();
+    tile = s_tile;
+  }
+
+  while (tile < n_tiles) {
+    // ---- 1. stage the tile: vertex, first edge, degree ----------------------
+    const std::size_t idx = (std::size_t)tile * ADV_BLOCK + tid;
+    vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
+    edge_t first = 0;
+    unsigned deg = 0;
+    if (idx < n_in) {
+      v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      if (util::limits::is_valid(v)) {
+        first = G.get_starting_edge(v);
+        deg = (unsigned)(G.get_starting_edge(v + 1) - first);
+      }
+    }
+    // ---- 2. hubs leave the tile as equal chunks -----------------------------
+    if (!HOLES && deg >= hub_threshold) {
+      if (spill_hub(v, first, deg, chunks, chunk_capacity, counters))
+        deg = 0;
+      // else: the queue is full; this list is expanded in place (slow, correct)
+    }
+    s_vertex[tid] = v;
+    s_first[tid] = first;
+    unsigned total;
+    const unsigned excl = block_exclusive_sum<ADV_BLOCK>(deg, total, s_wave_totals);
+    s_scan[tid] = excl;
+    if (HOLES && HAS_OUT && tid == 0)
+      s_base = total ? atomicAdd(&counters[C_OUT], (unsigned long long)total) : 0ull;
+    __syncthreads();
+
+    // ---- 3. stride the concatenated neighbour lists -------------------------
+    for (unsigned i0 = 0; i0 < total; i0 += ADV_BLOCK * ADV_UNROLL) {
+      vertex_t src[ADV_UNROLL], nbr[ADV_UNROLL];
+      edge_t eid[ADV_UNROLL];
+      weight_t wgt[ADV_UNROLL];
+      bool live[ADV_UNROLL];
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        const unsigned i = i0 + k * ADV_BLOCK + tid;
+        live[k] = i < total;
+        if (live[k]) {
+          const int slot = rightmost_le(s_scan, i, ADV_BLOCK);
+          src[k] = s_vertex[slot];
+          eid[k] = s_first[slot] + (edge_t)(i - s_scan[slot]);
+          nbr[k] = G.get_destination_vertex(eid[k]);
+          wgt[k] = G.get_edge_weight(eid[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        bool keep = false;
+        if (live[k])
+          keep = op(src[k], nbr[k], eid[k], wgt[k]);
+        if constexpr (HAS_OUT) {
+          if constexpr (HOLES) {
+            if (live[k]) {
+              const unsigned long long at = s_base + i0 + k * ADV_BLOCK + tid;
+              if (at < capacity)
+                output[at] = keep ? nbr[k] : gunrock::numeric_limits<vertex_t>::invalid();
+              else
+                counters[C_OVERFLOW] = 1ull;
+            }
+          } else {
+            wq.push(keep, nbr[k], output, capacity, counters);
+          }
+        }
+      }
+    }
+
+    // ---- 4. one cursor atomic per tile --------------------------------------
+    if constexpr (HAS_OUT && !HOLES)
+      drain_block(wq, s_counts, &s_base, output, capacity, counters);
+    else
+      __syncthreads();  // LDS tile arrays are rewritten by the next tile
+
+    if (DYNAMIC) {
+      if (tid == 0)
+        s_tile = atomicAdd(&counters[C_TILE], 1ull);
+      __syncthreads();
+      tile = s_tile;
+    } else {
+      tile += gridDim.x;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Hub chunks: persistent workgroups, one chunk (<= ADV_CHUNK consecutive edges of
+// one source) at a time, lanes on consecutive edges.
+// ---------------------------------------------------------------------------
+template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t, typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    chunk_kernel(graph_t G,
+                 op_t op,
+                 const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
+                 unsigned long long chunk_capacity,
+                 vertex_t* __restrict__ output,
+                 std::size_t capacity,
+                 unsigned long long* counters) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+
+  const int tid = threadIdx.x;
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+
+  unsigned long long n_chunks = counters[C_CHUNKS];
+  if (n_chunks > chunk_capacity)
+    n_chunks = chunk_capacity;  // the overflowed tail was expanded in place
+
+  for (unsigned long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const chunk_t<vertex_t, edge_t> d = chunks[c];
+    vertex_t source = d.source;
+    for (int j0 = 0; j0 < d.count; j0 += ADV_BLOCK * ADV_UNROLL) {
+      vertex_t nbr[ADV_UNROLL];
+      edge_t eid[ADV_UNROLL];
+      weight_t wgt[ADV_UNROLL];
+      bool live[ADV_UNROLL];
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        const int j = j0 + k * ADV_BLOCK + tid;
+        live[k] = j < d.count;
+        if (live[k]) {
+          eid[k] = d.first + (edge_t)j;
+          nbr[k] = G.get_destination_vertex(eid[k]);
+          wgt[k] = G.get_edge_weight(eid[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        bool keep = false;
+        if (live[k])
+          keep = op(source, nbr[k], eid[k], wgt[k]);
+        if constexpr (HAS_OUT)
+          wq.push(keep, nbr[k], output, capacity, counters);
+      }
+    }
+    if constexpr (HAS_OUT)
+      drain_block(wq, s_counts, &s_base, output, capacity, counters);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// thread_mapped: one lane per input slot (reference thread_mapped.hxx:59-95).
+// Packed output through the wavefront queue; holes output at segments[slot]+rank.
+// ---------------------------------------------------------------------------
+template <bool HOLES,
+          advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t,
+          typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    thread_mapped_kernel(graph_t G,
+                         op_t op,
+                         const vertex_t* __restrict__ input,
+                         std::size_t n_in,
+                         const edge_t* __restrict__ segments,
+                         vertex_t* __restrict__ output,
+                         std::size_t capacity,
+                         unsigned long long* counters) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+  const int tid = threadIdx.x;
+  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+
+  const std::size_t idx = blockIdx.x * (std::size_t)ADV_BLOCK + tid;
+  vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
+  edge_t first = 0;
+  edge_t deg = 0;
+  if (idx < n_in) {
+    v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+    if (util::limits::is_valid(v)) {
+      first = G.get_starting_edge(v);
+      deg = G.get_starting_edge(v + 1) - first;
+    }
+  }
+  // the wavefront iterates to its longest list; shorter lanes idle
+  const edge_t longest = wave_max(deg);
+  for (edge_t r = 0; r < longest; ++r) {
+    bool keep = false;
+    vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
+    if (r < deg) {
+      edge_t e = first + r;
+      n = G.get_destination_vertex(e);
+      weight_t w = G.get_edge_weight(e);
+      keep = op(v, n, e, w);
+      if constexpr (HAS_OUT && HOLES) {
+        const unsigned long long at = (unsigned long long)segments[idx] + (unsigned long long)r;
+        if (at < capacity)
+          output[at] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
+        else
+          counters[C_OVERFLOW] = 1ull;
+      }
+    }
+    if constexpr (HAS_OUT && !HOLES)
+      wq.push(keep, n, output, capacity, counters);
+  }
+  if constexpr (HAS_OUT && !HOLES)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+// ---------------------------------------------------------------------------
+// warp_mapped: one wavefront per input slot, 64 lanes stride the list.
+// ---------------------------------------------------------------------------
+template <advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    wave_mapped_kernel(graph_t G,
+                       op_t op,
+                       const vertex_t* __restrict__ input,
+                       std::size_t n_in,
+                       vertex_t* __restrict__ output,
+                       std::size_t capacity,
+                       unsigned long long* counters) {
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = tid / wave_size;
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u};
+
+  // a workgroup takes 4 * SLOTS_PER_WAVE consecutive slots, a wavefront SLOTS_PER_WAVE of them
+  constexpr int SLOTS_PER_WAVE = 16;
+  const std::size_t base_slot = ((std::size_t)blockIdx.x * ADV_WAVES + wave) * SLOTS_PER_WAVE;
+  for (int s = 0; s < SLOTS_PER_WAVE; ++s) {
+    const std::size_t idx = base_slot + s;
+    if (idx >= n_in)
+      break;  // wave-uniform
+    vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+    if (!util::limits::is_valid(v))
+      continue;
+    const edge_t first = G.get_starting_edge(v);
+    const edge_t deg = G.get_starting_edge(v + 1) - first;
+    for (edge_t r0 = 0; r0 < deg; r0 += wave_size) {
+      const edge_t r = r0 + lane;
+      bool keep = false;
+      vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
+      if (r < deg) {
+        edge_t e = first + r;
+        n = G.get_destination_vertex(e);
+        weight_t w = G.get_edge_weight(e);
+        keep = op(v, n, e, w);
+      }
+      if constexpr (HAS_OUT)
+        wq.push(keep, n, output, capacity, counters);
+    }
+  }
+  if constexpr (HAS_OUT)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+// ---------------------------------------------------------------------------
+// merge_path: segments[] = exclusive scan of the input slots' degrees
+// (segments[n_in] = total).  Every workgroup owns MP_TILE consecutive WORK ITEMS
+// (edges), finds the slots that overlap them, stages those in LDS and expands.
+// Output position in holes mode is the work-item index itself (deterministic,
+// like reference merge_path.hxx:104-105).
+// ---------------------------------------------------------------------------
+constexpr int MP_EPT = 4;
+constexpr int MP_TILE = ADV_BLOCK * MP_EPT;  // 1024 edges per workgroup
+constexpr int MP_SLOTS = 1024;               // slots staged in LDS per workgroup
+
+template <typename edge_t>
+__device__ __forceinline__ std::size_t global_rightmost_le(const edge_t* seg, std::size_t n,
+                                                           unsigned long long key) {
+  // largest s in [0, n) with seg[s] <= key  (seg[0] == 0 <= key)
+  std::size_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    std::size_t mid = lo + ((hi - lo) >> 1);
+    if ((unsigned long long)seg[mid] <= key)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+template <bool HOLES,
+          advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t,
+          typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    merge_path_kernel(graph_t G,
+                      op_t op,
+                      const vertex_t* __restrict__ input,
+                      std::size_t n_in,
+                      const edge_t* __restrict__ segments,
+                      unsigned long long total_work,
+                      vertex_t* __restrict__ output,
+                      std::size_t capacity,
+                      unsigned long long* counters) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ vertex_t s_vertex[MP_SLOTS];
+  __shared__ edge_t s_first[MP_SLOTS];
+  __shared__ edge_t s_seg[MP_SLOTS];
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+  const int tid = threadIdx.x;
+  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+
+  const unsigned long long w0 = (unsigned long long)blockIdx.x * MP_TILE;
+  if (w0 >= total_work)
+    return;
+  const unsigned long long w1 = (w0 + MP_TILE < total_work) ? w0 + MP_TILE : total_work;
+
+  // slots overlapping [w0, w1): every lane runs the same two searches (broadcast loads)
+  const std::size_t slot_lo = global_rightmost_le(segments, n_in, w0);
+  const std::size_t slot_hi = global_rightmost_le(segments, n_in, w1 - 1);
+  const std::size_t n_slots = slot_hi - slot_lo + 1;
+  const bool staged = n_slots <= (std::size_t)MP_SLOTS;
+  if (staged) {
+    for (std::size_t s = tid; s < n_slots; s += ADV_BLOCK) {
+      const std::size_t idx = slot_lo + s;
+      vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      s_vertex[s] = v;
+      s_seg[s] = segments[idx];
+      s_first[s] = util::limits::is_valid(v) ? G.get_starting_edge(v) : (edge_t)0;
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int k = 0; k < MP_EPT; ++k) {
+    const unsigned long long i = w0 + (unsigned long long)k * ADV_BLOCK + tid;
+    bool keep = false;
+    vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
+    if (i < w1) {
+      vertex_t v;
+      edge_t e;
+      if (staged) {
+        const int s = rightmost_le(s_seg, (edge_t)i, (int)n_slots);
+        v = s_vertex[s];
+        e = s_first[s] + ((edge_t)i - s_seg[s]);
+      } else {
+        const std::size_t idx = slot_lo + global_rightmost_le(segments + slot_lo, n_slots, i);
+        v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+        e = G.get_starting_edge(v) + ((edge_t)i - segments[idx]);
+      }
+      n = G.get_destination_vertex(e);
+      weight_t w = G.get_edge_weight(e);
+      keep = op(v, n, e, w);
+      if constexpr (HAS_OUT && HOLES) {
+        if (i < capacity)
+          output[i] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
+        else
+          counters[C_OVERFLOW] = 1ull;
+      }
+    }
+    if constexpr (HAS_OUT && !HOLES)
+      wq.push(keep, n, output, capacity, counters);
+  }
+  if constexpr (HAS_OUT && !HOLES)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+/// Degree of every input slot (0 for invalid), written for the device-wide scan.
+template <advance_io_type_t IN, typename graph_t, typename vertex_t, typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    slot_degree_kernel(graph_t G, const vertex_t* input, std::size_t n_in, edge_t* degrees) {
+  for (std::size_t i = blockIdx.x * (std::size_t)ADV_BLOCK + threadIdx.x; i <= n_in;
+       i += (std::size_t)gridDim.x * ADV_BLOCK) {
+    edge_t d = 0;
+    if (i < n_in) {
+      vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)i : input[i];
+      if (util::limits::is_valid(v))
+        d = G.get_number_of_neighbors(v);
+    }
+    degrees[i] = d;  // entry n_in is the scan's sentinel (reference helpers.hxx:55-57)
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bucketing: bin valid input slots by degree into three queues.
+//   small  (< 16)            -> thread-per-slot        (thread_mapped_kernel)
+//   medium (< hub_threshold) -> wavefront-per-slot     (wave_mapped_kernel)
+//   large                    -> equal chunks           (chunk_kernel)
+// Davidson et al.'s SSSP schedule, which the reference names but leaves empty
+// (advance/bucketing.hxx:24-36).
+// ---------------------------------------------------------------------------
+constexpr unsigned BUCKET_SMALL = 16;
+
+template <advance_io_type_t IN, typename graph_t, typename vertex_t, typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    bucket_kernel(graph_t G,
+                  const vertex_t* __restrict__ input,
+                  std::size_t n_in,
+                  vertex_t* __restrict__ small_q,
+                  vertex_t* __restrict__ medium_q,
+                  chunk_t<vertex_t, edge_t>* chunks,
+                  unsigned long long chunk_capacity,
+                  unsigned hub_threshold,
+                  unsigned long long* counters) {
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  // two wavefront queues: small and medium ids
+  __shared__ vertex_t s_small[ADV_WAVES * ADV_WQCAP];
+  __shared__ vertex_t s_medium[ADV_WAVES * ADV_WQCAP];
+  const int tid = threadIdx.x;
+  const int wave = tid / wave_size;
+  const int lane = lane_id();
+  unsigned n_small = 0, n_medium = 0;  // wave-uniform
+  vertex_t* qs = s_small + wave * ADV_WQCAP;
+  vertex_t* qm = s_medium + wave * ADV_WQCAP;
+
+  auto flush = [&](vertex_t* q, unsigned& fill, vertex_t* out, int slot) {
+    if (fill == 0)
+      return;
+    unsigned long long base = 0;
+    if (lane == 0)
+      base = atomicAdd(&counters[slot], (unsigned long long)fill);
+    base = __shfl(base, 0, wave_size);
+    for (unsigned j = lane; j < fill; j += wave_size)
+      out[base + j] = q[j];
+    fill = 0;
+  };
+
+  const std::size_t stride = (std::size_t)gridDim.x * ADV_BLOCK;
+  const std::size_t rounds = (n_in + stride - 1) / stride;
+  for (std::size_t r = 0; r < rounds; ++r) {
+    const std::size_t idx = r * stride + blockIdx.x * (std::size_t)ADV_BLOCK + tid;
+    vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
+    unsigned deg = 0;
+    edge_t first = 0;
+    if (idx < n_in) {
+      v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      if (util::limits::is_valid(v)) {
+        first = G.get_starting_edge(v);
+        deg = (unsigned)(G.get_starting_edge(v + 1) - first);
+      }
+    }
+    const bool is_small = deg > 0 && deg < BUCKET_SMALL;
+    bool is_medium = deg >= BUCKET_SMALL && deg < hub_threshold;
+    if (deg >= hub_threshold) {
+      if (!spill_hub(v, first, deg, chunks, chunk_capacity, counters))
+        is_medium = true;  // queue full: a wavefront walks it
+    }
+    unsigned long long ms = __ballot(is_small);
+    if (ms) {
+      if (n_small + wave_size > (unsigned)ADV_WQCAP)
+        flush(qs, n_small, small_q, C_BUCKET0);
+      if (is_small)
+        qs[n_small + rank_in_mask(ms)] = v;
+      n_small += (unsigned)__popcll(ms);
+    }
+    unsigned long long mm = __ballot(is_medium);
+    if (mm) {
+      if (n_medium + wave_size > (unsigned)ADV_WQCAP)
+        flush(qm, n_medium, medium_q, C_BUCKET0 + 1);
+      if (is_medium)
+        qm[n_medium + rank_in_mask(mm)] = v;
+      n_medium += (unsigned)__popcll(mm);
+    }
+  }
+  flush(qs, n_small, small_q, C_BUCKET0);
+  flush(qm, n_medium, medium_q, C_BUCKET0 + 1);
+  (void)s_counts;
+  (void)s_base;
+}
+
+}  // namespace kernels
+}  // namespace hip
+}  // namespace gunrock

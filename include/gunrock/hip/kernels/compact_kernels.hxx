@@ -1,0 +1,125 @@
+/**
+ * @file compact_kernels.hxx
+ * @brief Hand-written gfx950 stream-compaction kernels behind filter / uniquify.
+ *
+ * Replaces thrust::transform / copy_if / remove_copy_if / unique[_copy] and
+ * mgpu::transform_compact of the reference (filter/bypass.hxx:39-45,
+ * predicated.hxx:29-35, remove.hxx:28-34, compact.hxx:20-36, uniquify/unique*.hxx).
+ *
+ * Stable two-pass compaction, 64-lane ballots as the unit:
+ *   pass 1 (flag_kernel)  : every wavefront evaluates the predicate ONCE per element
+ *                           for 64 consecutive elements, stores the 64-bit ballot
+ *                           word and adds its popcount to the tile's count;
+ *   scan                  : exclusive scan of the per-tile counts (rocPRIM);
+ *   pass 2 (place_kernel) : re-reads the ballot words (the predicate is NOT called
+ *                           again: client predicates have side effects,
+ *                           algorithms/sssp.hxx:126-136), ranks each kept lane with
+ *                           mbcnt and writes it at tile base + word prefix + rank.
+ * A tile is CMP_TILE = 256 threads x 4 items = 1024 consecutive elements = 16 words.
+ */
+#pragma once
+
+#include <gunrock/hip/primitives.hxx>
+#include <gunrock/util/type_limits.hxx>
+
+namespace gunrock {
+namespace hip {
+namespace kernels {
+
+constexpr int CMP_BLOCK = 256;
+constexpr int CMP_ITEMS = 4;
+constexpr int CMP_TILE = CMP_BLOCK * CMP_ITEMS;          // 1024 elements
+constexpr int CMP_WORDS = CMP_TILE / wave_size;          // 16 ballot words per tile
+
+/// out[i] = valid(in[i]) && op(in[i]) ? in[i] : invalid   (filter::bypass)
+template <typename type_t, typename op_t>
+__global__ void __launch_bounds__(CMP_BLOCK)
+    bypass_kernel(const type_t* in, std::size_t n, type_t* out, op_t op) {
+  for (std::size_t i = blockIdx.x * (std::size_t)CMP_BLOCK + threadIdx.x; i < n;
+       i += (std::size_t)gridDim.x * CMP_BLOCK) {
+    type_t v = in[i];
+    bool keep = false;
+    if (util::limits::is_valid(v))
+      keep = op(v);
+    out[i] = keep ? v : gunrock::numeric_limits<type_t>::invalid();
+  }
+}
+
+/**
+ * @brief Pass 1.  flag(i, value) decides; it is called exactly once for every
+ * i < n, in no particular order.
+ */
+template <typename type_t, typename flag_t>
+__global__ void __launch_bounds__(CMP_BLOCK)
+    flag_kernel(const type_t* in, std::size_t n, unsigned long long* words,
+                unsigned* tile_counts, flag_t flag) {
+  __shared__ unsigned s_count;
+  if (threadIdx.x == 0)
+    s_count = 0;
+  __syncthreads();
+  const std::size_t tile0 = (std::size_t)blockIdx.x * CMP_TILE;
+  const int lane = lane_id();
+  unsigned mine = 0;
+#pragma unroll
+  for (int k = 0; k < CMP_ITEMS; ++k) {
+    const std::size_t i = tile0 + (std::size_t)k * CMP_BLOCK + threadIdx.x;
+    bool keep = false;
+    if (i < n)
+      keep = flag(i, in[i]);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) {
+      words[i / wave_size] = m;  // i is a multiple of 64 on lane 0
+      mine += (unsigned)__popcll(m);
+    }
+  }
+  if (lane == 0 && mine)
+    atomicAdd(&s_count, mine);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tile_counts[blockIdx.x] = s_count;
+}
+
+/// Pass 2.  tile_offsets = exclusive scan of tile_counts.
+template <typename type_t>
+__global__ void __launch_bounds__(CMP_BLOCK)
+    place_kernel(const type_t* in, std::size_t n, const unsigned long long* words,
+                 const unsigned* tile_offsets, type_t* out) {
+  __shared__ unsigned s_prefix[CMP_WORDS];
+  const std::size_t tile0 = (std::size_t)blockIdx.x * CMP_TILE;
+  const std::size_t word0 = tile0 / wave_size;
+  const std::size_t n_words = (n + wave_size - 1) / wave_size;
+  if (threadIdx.x < CMP_WORDS) {
+    // word-level exclusive prefix inside the tile, by the first 16 lanes of wave 0
+    unsigned long long m = (word0 + threadIdx.x < n_words) ? words[word0 + threadIdx.x] : 0ull;
+    unsigned c = (unsigned)__popcll(m);
+    unsigned incl = c;
+#pragma unroll
+    for (int d = 1; d < CMP_WORDS; d <<= 1) {
+      unsigned y = __shfl_up(incl, d, wave_size);
+      if ((int)threadIdx.x >= d)
+        incl += y;
+    }
+    s_prefix[threadIdx.x] = incl - c;
+  }
+  __syncthreads();
+  const unsigned base = tile_offsets[blockIdx.x];
+  const int wave = threadIdx.x / wave_size;
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < CMP_ITEMS; ++k) {
+    const std::size_t i = tile0 + (std::size_t)k * CMP_BLOCK + threadIdx.x;
+    const int w = k * (CMP_BLOCK / wave_size) + wave;
+    if (word0 + w >= n_words)
+      continue;
+    const unsigned long long m = words[word0 + w];
+    if ((m >> lane) & 1ull)
+      out[(std::size_t)base + s_prefix[w] + rank_in_mask(m)] = in[i];
+  }
+}
+
+/// Number of tiles for n elements.
+inline std::size_t compaction_tiles(std::size_t n) { return (n + CMP_TILE - 1) / CMP_TILE; }
+
+}  // namespace kernels
+}  // namespace hip
+}  // namespace gunrock

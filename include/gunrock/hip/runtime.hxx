@@ -1,0 +1,207 @@
+/**
+ * @file runtime.hxx
+ * @brief HIP runtime layer of the MI355X-native frontier engine: error
+ * convention, memory spaces, owning device / pinned-host buffers.
+ *
+ * Replaces (own implementation, gfx950 only): reference include/gunrock/error.hxx:21-46
+ * (exception_t / throw_if_exception), include/gunrock/memory.hxx:33-122
+ * (memory_space_t, allocate/free/raw_pointer_cast) and the thrust::device_vector
+ * storage behind container/vector.hxx:26-31.  No thrust, no CUB: storage is plain
+ * hipMalloc / hipHostMalloc so nothing on the operator path allocates implicitly.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace gunrock {
+
+namespace error {
+
+using error_t = hipError_t;
+
+/// Exceptions are the error convention of the C++ surface (reference error.hxx:21-46).
+struct exception_t : std::exception {
+  std::string report;
+  explicit exception_t(error_t status, std::string message = "")
+      : report(std::string(hipGetErrorString(status)) + "\t: " + message) {}
+  explicit exception_t(std::string message = "") : report(std::move(message)) {}
+  const char* what() const noexcept override { return report.c_str(); }
+};
+
+inline void throw_if_exception(error_t status, std::string message = "") {
+  if (status != hipSuccess)
+    throw exception_t(status, std::move(message));
+}
+
+inline void throw_if_exception(bool is_exception, std::string message = "") {
+  if (is_exception)
+    throw exception_t(std::move(message));
+}
+
+}  // namespace error
+
+/// Every HIP call on the engine's path is checked.
+#define GRX_HIP_CHECK(expr) \
+  ::gunrock::error::throw_if_exception((expr), #expr " @ " __FILE__ ":" + std::to_string(__LINE__))
+
+namespace memory {
+
+enum memory_space_t { device, host };
+
+template <typename type_t>
+inline type_t* allocate(std::size_t bytes, memory_space_t space = memory_space_t::device) {
+  void* p = nullptr;
+  if (bytes) {
+    if (space == memory_space_t::device)
+      GRX_HIP_CHECK(hipMalloc(&p, bytes));
+    else
+      GRX_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  }
+  return reinterpret_cast<type_t*>(p);
+}
+
+template <typename type_t>
+inline void free(type_t* p, memory_space_t space = memory_space_t::device) {
+  if (!p)
+    return;
+  if (space == memory_space_t::device)
+    (void)hipFree(p);
+  else
+    (void)hipHostFree(p);
+}
+
+template <typename type_t>
+__host__ __device__ inline type_t* raw_pointer_cast(type_t* p) {
+  return p;
+}
+
+}  // namespace memory
+
+namespace hip {
+
+/**
+ * @brief Owning, growable device array.  Growth preserves contents (needed by
+ * frontier_t::push_back / reserve); the engine sizes buffers up front so that no
+ * allocation happens inside the BSP loop in the steady state.
+ */
+template <typename type_t>
+class buffer_t {
+ public:
+  buffer_t() = default;
+  explicit buffer_t(std::size_t n) { reserve(n); }
+  buffer_t(const buffer_t&) = delete;
+  buffer_t& operator=(const buffer_t&) = delete;
+  buffer_t(buffer_t&& o) noexcept : ptr_(o.ptr_), cap_(o.cap_) { o.ptr_ = nullptr; o.cap_ = 0; }
+  buffer_t& operator=(buffer_t&& o) noexcept {
+    if (this != &o) {
+      release();
+      ptr_ = o.ptr_; cap_ = o.cap_;
+      o.ptr_ = nullptr; o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~buffer_t() { release(); }
+
+  type_t* data() const { return ptr_; }
+  std::size_t capacity() const { return cap_; }
+
+  /// Grow to at least n elements, keeping the first `keep` elements.
+  void reserve(std::size_t n, std::size_t keep = 0, hipStream_t stream = nullptr) {
+    if (n <= cap_)
+      return;
+    type_t* fresh = memory::allocate<type_t>(n * sizeof(type_t));
+    if (ptr_ && keep) {
+      GRX_HIP_CHECK(hipMemcpyAsync(fresh, ptr_, keep * sizeof(type_t), hipMemcpyDeviceToDevice, stream));
+      GRX_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    release();
+    ptr_ = fresh;
+    cap_ = n;
+  }
+
+  void release() {
+    if (ptr_)
+      (void)hipFree(ptr_);
+    ptr_ = nullptr;
+    cap_ = 0;
+  }
+
+ private:
+  type_t* ptr_ = nullptr;
+  std::size_t cap_ = 0;
+};
+
+/**
+ * @brief Sized device array (the engine's stand-in for a device vector where a
+ * size matters: the enactor's scan workspace, owning CSR arrays).
+ */
+template <typename type_t>
+class device_array_t {
+ public:
+  device_array_t() = default;
+  explicit device_array_t(std::size_t n) { resize(n); }
+  device_array_t(const type_t* host, std::size_t n) { assign(host, n); }
+
+  std::size_t size() const { return size_; }
+  std::size_t capacity() const { return buf_.capacity(); }
+  type_t* data() const { return buf_.data(); }
+  bool empty() const { return size_ == 0; }
+
+  void resize(std::size_t n) {
+    if (n > buf_.capacity())
+      buf_.reserve(n, size_);
+    size_ = n;
+  }
+  void assign(const type_t* host, std::size_t n) {
+    resize(n);
+    if (n)
+      GRX_HIP_CHECK(hipMemcpy(buf_.data(), host, n * sizeof(type_t), hipMemcpyHostToDevice));
+  }
+  void assign(const std::vector<type_t>& host) { assign(host.data(), host.size()); }
+  std::vector<type_t> to_host() const {
+    std::vector<type_t> h(size_);
+    if (size_)
+      GRX_HIP_CHECK(hipMemcpy(h.data(), buf_.data(), size_ * sizeof(type_t), hipMemcpyDeviceToHost));
+    return h;
+  }
+  void zero(hipStream_t stream = nullptr) {
+    if (size_)
+      GRX_HIP_CHECK(hipMemsetAsync(buf_.data(), 0, size_ * sizeof(type_t), stream));
+  }
+
+ private:
+  buffer_t<type_t> buf_;
+  std::size_t size_ = 0;
+};
+
+/// Pinned host words the device copies counters into (one D2H per operator).
+template <typename type_t>
+class pinned_t {
+ public:
+  explicit pinned_t(std::size_t n = 1) : n_(n) {
+    ptr_ = memory::allocate<type_t>(n * sizeof(type_t), memory::memory_space_t::host);
+    std::memset(ptr_, 0, n * sizeof(type_t));
+  }
+  pinned_t(const pinned_t&) = delete;
+  pinned_t& operator=(const pinned_t&) = delete;
+  ~pinned_t() { if (ptr_) (void)hipHostFree(ptr_); }
+  type_t* data() const { return ptr_; }
+  type_t& operator[](std::size_t i) const { return ptr_[i]; }
+  std::size_t size() const { return n_; }
+
+ private:
+  type_t* ptr_ = nullptr;
+  std::size_t n_ = 0;
+};
+
+}  // namespace hip
+}  // namespace gunrock

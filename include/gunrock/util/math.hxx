@@ -1,0 +1,190 @@
+/**
+ * @file math.hxx
+ * @brief Integer helpers and the device atomics facade used by client lambdas.
+ *
+ * Surface of reference include/gunrock/util/math.hxx:24-129 and
+ * include/gunrock/cuda/atomic_functions.hxx:36-123 (atomic::{add,min,max,cas,exch}
+ * return the OLD value).  gfx950 implementation notes:
+ *  - float min/max are ONE integer atomic on the IEEE bit pattern (sign-split
+ *    trick) instead of the reference's compare-and-swap loop;
+ *  - min/max first read the word with a relaxed agent-scope load and skip the
+ *    read-modify-write when it cannot change the word.  Device-scope RMWs execute
+ *    at the memory side on MI355X (they bypass the per-XCD L2), so a BFS/SSSP
+ *    relaxation that loses -- the overwhelming majority on a power-law graph --
+ *    costs one L2-served load instead of a fabric atomic.  The value returned in
+ *    that case was in memory during the call, which is all a relaxed atomic
+ *    promises.  Define GRX_ATOMIC_NO_PRETEST to disable.
+ *  - the host side of these functions really updates memory (the reference's host
+ *    branch returns without storing, SURVEY.md 8a' q4).
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace gunrock {
+namespace math {
+
+template <typename type_t>
+__host__ __device__ __forceinline__ constexpr type_t divide_round_up(type_t const& a,
+                                                                      type_t const& b) {
+  return (a + b - 1) / b;
+}
+
+template <typename type_t>
+constexpr type_t log2(const type_t& n) {
+  return (n < 2) ? 0 : 1 + log2(n / 2);
+}
+
+template <typename type_t>
+__host__ __device__ constexpr const type_t& max(const type_t& a, const type_t& b) {
+  return (a < b) ? b : a;
+}
+
+template <typename type_t>
+__host__ __device__ constexpr const type_t& min(const type_t& a, const type_t& b) {
+  return (b < a) ? b : a;
+}
+
+namespace atomic {
+
+namespace detail {
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename type_t>
+__device__ __forceinline__ type_t peek(type_t* address) {
+  return __hip_atomic_load(address, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float fmin_rmw(float* address, float value) {
+  // IEEE-754 order equals signed-int order for non-negative values and reversed
+  // unsigned order for negative ones.
+  return (value >= 0.0f)
+             ? __int_as_float(::atomicMin(reinterpret_cast<int*>(address), __float_as_int(value)))
+             : __uint_as_float(
+                   ::atomicMax(reinterpret_cast<unsigned int*>(address), __float_as_uint(value)));
+}
+__device__ __forceinline__ float fmax_rmw(float* address, float value) {
+  return (value >= 0.0f)
+             ? __int_as_float(::atomicMax(reinterpret_cast<int*>(address), __float_as_int(value)))
+             : __uint_as_float(
+                   ::atomicMin(reinterpret_cast<unsigned int*>(address), __float_as_uint(value)));
+}
+__device__ __forceinline__ double dmin_rmw(double* address, double value) {
+  return (value >= 0.0)
+             ? __longlong_as_double(::atomicMin(reinterpret_cast<long long*>(address),
+                                                __double_as_longlong(value)))
+             : __longlong_as_double((long long)::atomicMax(
+                   reinterpret_cast<unsigned long long*>(address),
+                   (unsigned long long)__double_as_longlong(value)));
+}
+__device__ __forceinline__ double dmax_rmw(double* address, double value) {
+  return (value >= 0.0)
+             ? __longlong_as_double(::atomicMax(reinterpret_cast<long long*>(address),
+                                                __double_as_longlong(value)))
+             : __longlong_as_double((long long)::atomicMin(
+                   reinterpret_cast<unsigned long long*>(address),
+                   (unsigned long long)__double_as_longlong(value)));
+}
+#endif
+}  // namespace detail
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t add(type_t* address, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ::atomicAdd(address, value);
+#else
+  type_t old = *address;
+  *address = old + value;
+  return old;
+#endif
+}
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t min(type_t* address, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef GRX_ATOMIC_NO_PRETEST
+  type_t seen = detail::peek(address);
+  if (!(value < seen))
+    return seen;
+#endif
+  if constexpr (std::is_same<type_t, float>::value)
+    return detail::fmin_rmw(address, value);
+  else if constexpr (std::is_same<type_t, double>::value)
+    return detail::dmin_rmw(address, value);
+  else
+    return ::atomicMin(address, value);
+#else
+  type_t old = *address;
+  if (value < old)
+    *address = value;
+  return old;
+#endif
+}
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t max(type_t* address, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef GRX_ATOMIC_NO_PRETEST
+  type_t seen = detail::peek(address);
+  if (!(seen < value))
+    return seen;
+#endif
+  if constexpr (std::is_same<type_t, float>::value)
+    return detail::fmax_rmw(address, value);
+  else if constexpr (std::is_same<type_t, double>::value)
+    return detail::dmax_rmw(address, value);
+  else
+    return ::atomicMax(address, value);
+#else
+  type_t old = *address;
+  if (old < value)
+    *address = value;
+  return old;
+#endif
+}
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t cas(type_t* address, type_t compare, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ::atomicCAS(address, compare, value);
+#else
+  type_t old = *address;
+  if (old == compare)
+    *address = value;
+  return old;
+#endif
+}
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t exch(type_t* address, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ::atomicExch(address, value);
+#else
+  type_t old = *address;
+  *address = value;
+  return old;
+#endif
+}
+
+}  // namespace atomic
+}  // namespace math
+
+/// Plain (default cache policy) element load / store used by the graph views
+/// and by client lambdas (reference util/load_store.hxx:23-42).
+namespace thread {
+
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t load(type_t* ptr) {
+  return *ptr;
+}
+
+template <typename type_t>
+__host__ __device__ __forceinline__ void store(type_t* ptr, const type_t& val) {
+  *ptr = val;
+}
+
+}  // namespace thread
+}  // namespace gunrock

@@ -1,0 +1,331 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- needs an MI355X.
+
+Every test here calls libessentials_amd.so; the oracle (oracle/) is only the checker.
+Integer / id results are compared bit-exactly; SSSP on integer-valued weights is
+bit-exact too (the fix point is unique and every partial sum is exact); PageRank
+uses an explicit tolerance (float atomics land in arbitrary order).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_graph
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+INF_I = 2**31 - 1
+INF_F = np.finfo(np.float32).max
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ea():
+    import essentials_amd
+    return essentials_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx(ea, torch):
+    c = ea.Context(0)
+    info = c.device_info()
+    assert info["wavefront_size"] == 64
+    return c
+
+
+ALL_LB = ["block_mapped", "merge_path", "bucketing", "work_stealing", "thread_mapped", "warp_mapped"]
+HOLES_LB = ["block_mapped", "merge_path", "thread_mapped"]
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# inputs: generator and loaders
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,ef,seed,wseed,sym", [(8, 16, 1, 7, True), (10, 16, 1, 0, True),
+                                                     (12, 16, 1, 7, True), (10, 8, 3, 5, False),
+                                                     (14, 16, 1, 0, True)])
+def test_rmat_generator_bit_exact(ea, ctx, oracle, scale, ef, seed, wseed, sym):
+    g = ea.Graph.rmat(ctx, scale, ef, seed, wseed, sym)
+    ap, aj, ax = g.to_host()
+    n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, seed, wseed, sym)
+    assert g.n_rows == n and g.nnz == len(Aj)
+    assert (ap == Ap).all() and (aj == Aj).all() and (ax == Ax).all()
+
+
+def test_mtx_loader_matches_oracle(ea, ctx, oracle, tmp_path):
+    g = ea.Graph.from_mtx(os.path.join(GOLDEN_DIR, "chesapeake.mtx"))
+    ap, aj, ax = g.to_host()
+    n, Ap, Aj, Ax = oracle.mtx_to_csr(os.path.join(GOLDEN_DIR, "chesapeake.mtx"))
+    assert (ap == Ap).all() and (aj == Aj).all() and (ax == Ax).all()
+    p = str(tmp_path / "c.csr")
+    g.write_csr_file(p)
+    n2, m2, Ap2, Aj2, Ax2 = oracle.csr_read_binary(p)      # reference .csr layout
+    assert n2 == 39 and (Ap2 == Ap).all() and (Aj2 == Aj).all() and (Ax2 == Ax).all()
+    g2 = ea.Graph.from_csr_file(p)
+    ap2, aj2, ax2 = g2.to_host()
+    assert (ap2 == Ap).all() and (aj2 == Aj).all() and (ax2 == Ax).all()
+    with pytest.raises(ea.EngineError):
+        ea.Graph.from_mtx(str(tmp_path / "missing.mtx"))
+
+
+# ---------------------------------------------------------------------------
+# the three clients on the golden vectors
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("lb", ALL_LB)
+def test_bfs_golden(ea, ctx, oracle, golden, lb):
+    for name, g in golden.items():
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for run in g["runs"]:
+            d, st = ea.bfs(ctx, G, run["source"], options=ea.Options(load_balance=ea.LoadBalance[lb]))
+            d = host(d)
+            assert sha(d) == run["bfs_sha256"], (name, run["source"], lb)
+            assert st.vertices_reached == run["reached"]
+            assert st.edges_traversed == run["edges_traversed"]
+            # packed frontiers: one loop() per BFS level plus the empty-output one
+            assert st.iterations == run["max_depth"] + 1, (name, lb, st)
+
+
+@pytest.mark.parametrize("lb", HOLES_LB)
+def test_bfs_golden_holes_layout(ea, ctx, oracle, golden, lb):
+    """Reference output layout: one slot per traversed edge, -1 holes."""
+    for name in ("chesapeake", "sample4x4", "tc4", "rmat8_w0", "rmat10_w7", "rmat10_directed"):
+        g = golden[name]
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for run in g["runs"]:
+            d, st = ea.bfs(ctx, G, run["source"],
+                           options=ea.Options(load_balance=ea.LoadBalance[lb], holes_layout=True))
+            assert sha(host(d)) == run["bfs_sha256"], (name, lb)
+            _, tr = oracle.bfs_frontier(Ap, Aj, Ax, run["source"])
+            assert st.iterations == tr.iterations
+            assert st.frontier_slots == list(tr.frontier_slots[: tr.iterations]), (name, lb)
+
+
+def test_chesapeake_reference_trace(ea, ctx):
+    """4 loop() calls, input slots 1 / 11 / 124 / 205."""
+    G = ea.Graph.from_mtx(os.path.join(GOLDEN_DIR, "chesapeake.mtx"))
+    d, st = ea.bfs(ctx, G, 0, options=ea.Options(holes_layout=True))
+    assert st.iterations == 4 and st.frontier_slots == [1, 11, 124, 205]
+    assert host(d).tolist() == [0, 2, 2, 2, 2, 2, 1, 1, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1,
+                                2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 2, 1, 2, 1]
+    d, st = ea.bfs(ctx, G, 0)                       # packed (default) layout
+    assert st.iterations == 3 and st.frontier_slots == [1, 11, 27]
+    assert st.edges_traversed == 340 and st.vertices_reached == 39
+
+
+@pytest.mark.parametrize("lb", ALL_LB)
+def test_sssp_golden_bit_exact(ea, ctx, oracle, golden, lb):
+    for name, g in golden.items():
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for run in g["runs"]:
+            d, st = ea.sssp(ctx, G, run["source"], options=ea.Options(load_balance=ea.LoadBalance[lb]))
+            assert sha(host(d).view(np.uint32)) == run["sssp_bits_sha256"], (name, run["source"], lb)
+
+
+def test_sssp_holes_layout(ea, ctx, oracle, golden):
+    for name in ("chesapeake", "rmat8_w7", "rmat10_w7"):
+        g = golden[name]
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for run in g["runs"]:
+            d, st = ea.sssp(ctx, G, run["source"], options=ea.Options(holes_layout=True))
+            assert sha(host(d).view(np.uint32)) == run["sssp_bits_sha256"], name
+
+
+@pytest.mark.parametrize("lb", ["block_mapped", "merge_path", "bucketing"])
+def test_pagerank_against_restatement(ea, ctx, oracle, lb):
+    """Reference has no PageRank checker (parity unpinned); tolerance 5e-6 absolute on
+    ranks that sum to 1 (float atomics land in arbitrary order)."""
+    for scale, sym in ((10, False), (12, True)):
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, 8, 3, 0, sym)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        p, st = ea.pagerank(ctx, G, 0.85, 1e-6, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+        p = host(p)
+        assert abs(float(p.sum()) - 1.0) < 1e-3
+        assert np.abs(p - want).max() < 5e-6, (scale, lb, np.abs(p - want).max())
+        assert abs(st.iterations - it) <= 1
+
+
+# ---------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------
+def _frontier_cases(n, rng):
+    yield np.array([], np.int32)
+    yield np.array([-1, -1, -1], np.int32)
+    yield np.array([0], np.int32)
+    yield np.arange(n, dtype=np.int32)
+    f = rng.integers(0, n, 3 * n).astype(np.int32)       # duplicates are legal
+    f[rng.random(len(f)) < 0.3] = -1                     # ragged with holes
+    yield f
+    yield rng.integers(0, n, 257).astype(np.int32)       # one element past a tile
+
+
+@pytest.mark.parametrize("lb", ALL_LB)
+@pytest.mark.parametrize("holes", [False, True])
+def test_advance_matches_oracle(ea, ctx, torch, oracle, lb, holes):
+    rng = np.random.default_rng(5)
+    for (scale, ef, sym) in ((6, 4, True), (9, 8, False), (11, 16, True)):
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, 21, 9, sym)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        opts = ea.Options(load_balance=ea.LoadBalance[lb], holes_layout=holes, hub_threshold=64)
+        for f in _frontier_cases(n, rng):
+            calls = torch.zeros(max(len(Aj), 1), dtype=torch.int32, device="cuda")
+            ft = torch.from_numpy(f).cuda()
+            out = ea.advance(ctx, G, ft, ea.EdgeOp.count_edge, calls, 0, opts,
+                             capacity=max(16, 4 * len(Aj) + 16))
+            want_calls = np.zeros(max(len(Aj), 1), np.int64)
+
+            def op(s, d, e, w):
+                want_calls[e] += 1
+                return (s + d) % 3 == 0
+            want = oracle.advance(Ap, Aj, Ax, f, op)
+            got = host(out)
+            assert (host(calls) == want_calls).all(), (lb, holes, scale, len(f))   # exactly once
+            if holes:   # every schedule honours the layout (warp/bucketing route to merge_path)
+                assert len(got) == len(want)
+                assert sorted(got.tolist()) == sorted(want.tolist())
+            else:
+                assert sorted(got.tolist()) == sorted(want[want != -1].tolist()), (lb, holes, scale)
+        # graph as the input frontier, no output (PageRank's form)
+        acc = torch.zeros(n, dtype=torch.float32, device="cuda")
+        ea.advance(ctx, G, None, ea.EdgeOp.sum_weight, acc, 0, opts, want_output=False)
+        want_acc = np.zeros(n, np.float64)
+        np.add.at(want_acc, Aj, Ax.astype(np.float64))
+        assert np.array_equal(host(acc).astype(np.float64), want_acc)   # integer-valued weights: exact
+        # graph as the input frontier with an output
+        out = ea.advance(ctx, G, None, ea.EdgeOp.all, None, 0, opts)
+        assert sorted(host(out).tolist()) == sorted(Aj.tolist())
+
+
+def test_advance_hub_chunks(ea, ctx, torch, oracle):
+    """A star: one list far above the hub threshold, cut into chunks."""
+    n = 20000
+    Ap = np.zeros(n + 1, np.int32); Ap[1:] = n - 1                # vertex 0 -> everyone else
+    Aj = np.arange(1, n, dtype=np.int32); Ax = np.ones(n - 1, np.float32)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    for lb in ("block_mapped", "bucketing", "work_stealing"):
+        calls = torch.zeros(n - 1, dtype=torch.int32, device="cuda")
+        out = ea.advance(ctx, G, torch.tensor([0, -1, 0], dtype=torch.int32, device="cuda"),
+                         ea.EdgeOp.count_edge, calls, 0, ea.Options(load_balance=ea.LoadBalance[lb]))
+        assert (host(calls) == 2).all()
+        want = [v for v in range(1, n) if v % 3 == 0] * 2
+        assert sorted(host(out).tolist()) == sorted(want)
+
+
+def test_advance_capacity_error(ea, ctx, torch, oracle):
+    n, Ap, Aj, Ax = oracle.rmat_csr(8, 8, 2, 0, True)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    with pytest.raises(ea.EngineError):
+        ea.advance(ctx, G, None, ea.EdgeOp.all, None, 0, capacity=8)
+
+
+@pytest.mark.parametrize("alg", ["remove", "predicated", "compact", "bypass"])
+def test_filter_matches_oracle(ea, ctx, torch, oracle, alg):
+    rng = np.random.default_rng(3)
+    n, Ap, Aj, Ax = oracle.rmat_csr(8, 4, 1, 0, True)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    for size in (0, 1, 63, 64, 65, 1023, 1024, 1025, 5000, 100000):
+        f = rng.integers(0, n, size).astype(np.int32)
+        if size:
+            f[rng.random(size) < 0.25] = -1
+        ft = torch.from_numpy(f).cuda()
+        calls = torch.zeros(n, dtype=torch.int32, device="cuda")
+        got = host(ea.filter(ctx, G, ft, ea.FilterAlgorithm[alg], ea.VertexOp.count, calls))
+        want_calls = np.bincount(f[f != -1], minlength=n)
+        assert (host(calls) == want_calls).all()              # once per valid element, never on -1
+        pred = lambda v: v % 3 != 0
+        if alg == "bypass":
+            assert got.tolist() == oracle.filter_bypass(f, pred).tolist()
+        else:
+            assert got.tolist() == oracle.filter_keep(f, pred).tolist()   # stable
+    # the SSSP predicate (benign race: duplicates may survive, one copy at least is kept)
+    f = rng.integers(0, n, 4000).astype(np.int32)
+    stamp = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    got = host(ea.filter(ctx, G, torch.from_numpy(f).cuda(), ea.FilterAlgorithm.bypass,
+                         ea.VertexOp.once, stamp, 7))
+    kept = got[got != -1]
+    assert set(kept.tolist()) == set(f.tolist()) and (host(stamp)[np.unique(f)] == 7).all()
+    assert (got[got != -1] == f[got != -1]).all()
+
+
+@pytest.mark.parametrize("alg", ["unique", "unique_copy"])
+def test_uniquify_matches_oracle(ea, ctx, torch, oracle, alg):
+    rng = np.random.default_rng(9)
+    for size in (0, 1, 2, 64, 1000, 1025, 70000):
+        f = rng.integers(0, max(size // 3, 2), size).astype(np.int32)
+        ft = torch.from_numpy(f).cuda()
+        got = host(ea.uniquify(ctx, ft, ea.UniquifyAlgorithm[alg], best_effort=False))
+        assert got.tolist() == oracle.uniquify(f, sort=True).tolist()
+        got = host(ea.uniquify(ctx, ft, ea.UniquifyAlgorithm[alg], best_effort=True))
+        assert got.tolist() == oracle.uniquify(f, sort=False).tolist()
+
+
+# ---------------------------------------------------------------------------
+# larger seeded graphs against the oracle (seconds of CPU)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("lb", ["block_mapped", "merge_path", "bucketing", "work_stealing"])
+def test_bfs_sssp_rmat18_against_oracle(ea, ctx, oracle, lb):
+    g = ea.Graph.rmat(ctx, 18, 16, seed=1, weight_seed=7)
+    Ap, Aj, Ax = g.to_host()
+    deg = np.diff(Ap)
+    rng = np.random.default_rng(18)
+    sources = [0] + rng.choice(np.flatnonzero(deg > 0), 2).tolist()
+    for s in sources:
+        d, st = ea.bfs(ctx, g, int(s), options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        want, _ = oracle.bfs_heap(Ap, Aj, int(s))
+        assert (host(d) == want).all(), (lb, s)
+        assert st.edges_traversed == int(deg[want != INF_I].sum())
+    w, st = ea.sssp(ctx, g, 0, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+    want, _ = oracle.sssp_heap(Ap, Aj, Ax, 0)
+    assert (host(w).view(np.uint32) == want.view(np.uint32)).all(), lb
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's full size (RMAT-22): size-independent properties
+# ---------------------------------------------------------------------------
+def test_bfs_rmat22_properties(ea, ctx, torch):
+    g = ea.Graph.rmat(ctx, 22, 16, seed=1)
+    assert g.n_rows == 1 << 22 and 130_000_000 < g.nnz < 2**27
+    d0, st0 = ea.bfs(ctx, g, 0)
+    # (1) every schedule produces the same labels
+    for lb in ("merge_path", "bucketing", "work_stealing"):
+        d, st = ea.bfs(ctx, g, 0, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        assert torch.equal(d, d0), lb
+        assert st.edges_traversed == st0.edges_traversed
+    # (2) BFS certificate on the device: depth[src]=0; along every edge of a reached
+    #     vertex the depth drops by at most one; every reached non-source vertex has a
+    #     neighbour one level up (the graph is symmetric)
+    h_ap, h_aj, _ = g.to_host()
+    ap = torch.from_numpy(h_ap).cuda()
+    aj = torch.from_numpy(np.ascontiguousarray(h_aj)).cuda()
+    deg = (ap[1:] - ap[:-1]).long()
+    src = torch.repeat_interleave(torch.arange(g.n_rows, device="cuda", dtype=torch.int32), deg)
+    du = d0[src.long()].long(); dv = d0[aj.long()].long()
+    reached_u = du != INF_I
+    assert int(d0[0]) == 0
+    assert bool(((dv[reached_u] != INF_I)).all())                     # closed under edges
+    assert bool((dv[reached_u] <= du[reached_u] + 1).all())            # no edge skips a level
+    best = torch.full((g.n_rows,), INF_I, dtype=torch.int64, device="cuda")
+    best.scatter_reduce_(0, aj.long(), du, reduce="amin")              # min depth over in-neighbours
+    reached = d0 != INF_I
+    nonsrc = reached.clone(); nonsrc[0] = False
+    assert bool((best[nonsrc] + 1 == d0[nonsrc].long()).all())         # tight: parent exists
+    assert st0.vertices_reached == int(reached.sum())
+    assert st0.edges_traversed == int(deg[reached].sum())
