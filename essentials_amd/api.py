@@ -67,7 +67,7 @@ class _Options(C.Structure):
     _fields_ = [("load_balance", C.c_int32), ("holes_layout", C.c_int32),
                 ("hub_threshold", C.c_int32), ("max_iterations", C.c_int32),
                 ("frontier_sizing_factor", C.c_float), ("collect_kernel_time", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("chunk_edges", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class _Stats(C.Structure):
@@ -86,6 +86,7 @@ class Options:
     max_iterations: int = 0
     frontier_sizing_factor: float = 1.5
     collect_kernel_time: bool = False
+    chunk_edges: int = 0
 
     def _c(self) -> _Options:
         o = _Options()
@@ -95,6 +96,7 @@ class Options:
         o.max_iterations = int(self.max_iterations)
         o.frontier_sizing_factor = float(self.frontier_sizing_factor)
         o.collect_kernel_time = int(self.collect_kernel_time)
+        o.chunk_edges = int(self.chunk_edges)
         return o
 
 
@@ -375,6 +377,9 @@ def advance(ctx: Context, g: Graph, frontier, op: EdgeOp = EdgeOp.all, state=Non
     torch = _torch()
     o = (options or Options())._c()
     n_in = 0 if frontier is None else frontier.numel()
+    if frontier is not None and n_in == 0:
+        # an EMPTY frontier is not "the whole graph": hand the ABI a non-NULL pointer
+        frontier = torch.empty(1, dtype=torch.int32, device=f"cuda:{ctx.device}")
     out = None
     cap = 0
     if want_output:

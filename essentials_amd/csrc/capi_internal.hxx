@@ -99,6 +99,8 @@ struct scoped_options {
       ctx.options().holes_layout = opt->holes_layout != 0;
       if (opt->hub_threshold > 0)
         ctx.options().hub_threshold = (unsigned)opt->hub_threshold;
+      if (opt->chunk_edges > 0)
+        ctx.options().chunk_edges = (unsigned)opt->chunk_edges;
       ctx.options().time_kernels = opt->collect_kernel_time != 0;
     }
     ctx.kernel_clock().reset();

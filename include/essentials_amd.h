@@ -91,11 +91,12 @@ typedef struct grx_graph_s* grx_graph_t;     /* graph::graph_t over CSR, graph/b
 typedef struct grx_options {
   int32_t load_balance;     /* grx_load_balance; default GRX_LB_BLOCK_MAPPED (what bfs.hxx spells) */
   int32_t holes_layout;     /* 1: one output slot per traversed edge, -1 holes (reference layout) */
-  int32_t hub_threshold;    /* 0: default (2048)                                                  */
+  int32_t hub_threshold;    /* 0: default (1024): longer lists are cut into chunks               */
   int32_t max_iterations;   /* 0: run to convergence                                              */
   float frontier_sizing_factor; /* 0: default 1.5 (enactor.hxx:36)                                */
   int32_t collect_kernel_time;  /* 1: event-time the advance kernels (adds two events per launch)  */
-  int32_t reserved[2];
+  int32_t chunk_edges;          /* 0: default (1024): edges per chunk of a hub list                */
+  int32_t reserved[1];
 } grx_options;
 
 /* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the

@@ -81,7 +81,24 @@ class frontier_t {
 
   // --- size bookkeeping -----------------------------------------------------
   std::size_t get_number_of_elements(hipStream_t = nullptr) const { return num_elements_; }
-  void set_number_of_elements(std::size_t const& n) { num_elements_ = n; }
+  /// Changing the length from outside invalidates the work hint (see work_hint()).
+  void set_number_of_elements(std::size_t const& n) {
+    num_elements_ = n;
+    work_hint_ = unknown_work;
+  }
+
+  /**
+   * @brief Upper bound of the sum of the degrees of the valid elements, when an
+   * operator of this engine produced the contents (advance sums the degrees of
+   * what it emits; filters and uniquify only remove elements, so they pass the
+   * bound on).  unknown_work otherwise.  Lets the next advance size its output
+   * without the reference's reduction pass (advance/helpers.hxx:112-146).  Code
+   * that rewrites elements in place through data() must call invalidate_work_hint().
+   */
+  static constexpr unsigned long long unknown_work = ~0ull;
+  unsigned long long work_hint() const { return work_hint_; }
+  void set_work_hint(unsigned long long w) { work_hint_ = w; }
+  void invalidate_work_hint() { work_hint_ = unknown_work; }
   bool is_empty() const { return num_elements_ == 0; }
   std::size_t get_capacity() const { return storage_->capacity(); }
   float get_resizing_factor() const { return resizing_factor_; }
@@ -112,6 +129,7 @@ class frontier_t {
       GRX_HIP_CHECK(hipDeviceSynchronize());
     }
     num_elements_ = size;
+    work_hint_ = unknown_work;
   }
 
   /// Host-side append of one element (used by prepare_frontier, bfs.hxx:77).
@@ -120,9 +138,11 @@ class frontier_t {
       storage_->reserve(get_capacity() ? 2 * get_capacity() : 64, num_elements_);
     GRX_HIP_CHECK(hipMemcpy(data() + num_elements_, &value, sizeof(type_t), hipMemcpyHostToDevice));
     ++num_elements_;
+    work_hint_ = unknown_work;
   }
 
   void fill(type_t const value, hipStream_t stream = nullptr) {
+    work_hint_ = unknown_work;
     if (!num_elements_)
       return;
     detail::fill_kernel<<<detail::grid_for(num_elements_), 256, 0, stream>>>(data(), num_elements_,
@@ -134,6 +154,7 @@ class frontier_t {
     if (get_capacity() < size)
       reserve(size);
     num_elements_ = size;
+    work_hint_ = unknown_work;
     if (!size)
       return;
     detail::sequence_kernel<<<detail::grid_for(size), 256, 0, stream>>>(data(), size,
@@ -160,6 +181,7 @@ class frontier_t {
     std::swap(storage_, other.storage_);
     std::swap(num_elements_, other.num_elements_);
     std::swap(resizing_factor_, other.resizing_factor_);
+    std::swap(work_hint_, other.work_hint_);
   }
 
   std::vector<type_t> to_host() const {
@@ -181,6 +203,7 @@ class frontier_t {
   std::shared_ptr<hip::buffer_t<type_t>> storage_;
   std::size_t num_elements_ = 0;
   float resizing_factor_ = 1.0f;
+  unsigned long long work_hint_ = ~0ull;
 };
 
 }  // namespace frontier

@@ -86,7 +86,7 @@ unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
   unsigned long long* counters = ws.counters();
   GRX_HIP_CHECK(hipMemsetAsync(counters + k::C_MAXDEG, 0, sizeof(unsigned long long), ctx.stream()));
   if (n) {
-    k::max_degree_kernel<<<grid_for(n, k::ADV_BLOCK, 4096), k::ADV_BLOCK, 0, ctx.stream()>>>(
+    k::max_degree_kernel<<<grid_for(n, k::ADV_BLOCK, 1024), k::ADV_BLOCK, 0, ctx.stream()>>>(
         G, counters);
     GRX_HIP_CHECK(hipGetLastError());
   }
@@ -101,7 +101,7 @@ unsigned long long degree_sum(graph_t& G, const vertex_t* input, std::size_t n_i
                               gcuda::standard_context_t& ctx) {
   if (input_type == advance_io_type_t::graph)
     return (unsigned long long)G.get_number_of_edges();
-  k::degree_sum_kernel<input_type><<<grid_for(n_in, k::ADV_BLOCK, 4096), k::ADV_BLOCK, 0,
+  k::degree_sum_kernel<input_type><<<grid_for(n_in, k::ADV_BLOCK, 1024), k::ADV_BLOCK, 0,
                                      ctx.stream()>>>(G, input, n_in, ctx.workspace().counters());
   GRX_HIP_CHECK(hipGetLastError());
   return fetch_counters(ctx)[k::C_WORK];
@@ -124,7 +124,11 @@ template <advance_io_type_t input_type, typename graph_t, typename frontier_t>
 bool size_output(graph_t& G, frontier_t& input, frontier_t& output, std::size_t n_in, bool exact,
                  unsigned long long& total, gcuda::standard_context_t& ctx) {
   total = ~0ull;
-  const unsigned long long bound = saturating_mul(n_in, max_degree(G, ctx));
+  unsigned long long bound = saturating_mul(n_in, max_degree(G, ctx));
+  if (input_type != advance_io_type_t::graph && input.work_hint() < bound)
+    bound = input.work_hint();  // left by the operator that produced this frontier
+  if (input_type == advance_io_type_t::graph)
+    bound = (unsigned long long)G.get_number_of_edges();
   if (!exact && bound <= output.get_capacity())
     return true;
   total = degree_sum<input_type>(G, input.data(), n_in, ctx);
@@ -145,13 +149,16 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
   error::throw_if_exception(m[k::C_OVERFLOW] != 0,
                             "advance: output frontier capacity exceeded");
   output.set_number_of_elements(holes ? (std::size_t)total : (std::size_t)m[k::C_OUT]);
+  if (!holes)
+    output.set_work_hint(m[k::C_NEXT_WORK]);
 }
 
 /// Device chunk queue sized for every hub of the graph at once.
 template <typename vertex_t, typename edge_t, typename graph_t>
 k::chunk_t<vertex_t, edge_t>* chunk_queue(graph_t& G, unsigned long long& capacity,
                                           gcuda::standard_context_t& ctx) {
-  capacity = (unsigned long long)G.get_number_of_edges() / k::ADV_CHUNK + 65536;
+  const unsigned chunk_edges = ctx.options().chunk_edges ? ctx.options().chunk_edges : 1024u;
+  capacity = (unsigned long long)G.get_number_of_edges() / chunk_edges + 65536;
   return reinterpret_cast<k::chunk_t<vertex_t, edge_t>*>(
       ctx.workspace().queue(capacity * sizeof(k::chunk_t<vertex_t, edge_t>)));
 }
@@ -200,11 +207,11 @@ void execute(graph_t& G,
   unsigned long long chunk_capacity = 0;
   auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, chunk_capacity, context);
   const unsigned hub_threshold = context.options().hub_threshold;
+  const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
   unsigned long long* counters = context.workspace().counters();
   const std::size_t n_tiles = (n_in + k::ADV_BLOCK - 1) / k::ADV_BLOCK;
   const unsigned persistent = (unsigned)context.compute_units() * 8u;
-  const unsigned grid = dynamic_tiles ? (unsigned)(n_tiles < persistent ? n_tiles : persistent)
-                                      : detail::grid_for(n_tiles, 1);
+  const unsigned grid = (unsigned)(n_tiles < persistent ? n_tiles : persistent);
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
 
@@ -213,12 +220,12 @@ void execute(graph_t& G,
     k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,
-                                                      hub_threshold);
+                                                      hub_threshold, chunk_edges);
   } else {
     k::block_mapped_kernel<false, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,
-                                                      hub_threshold);
+                                                      hub_threshold, chunk_edges);
     if (max_deg >= hub_threshold) {
       k::chunk_kernel<output_type><<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0,
                                      context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr,
@@ -302,7 +309,7 @@ void execute(graph_t& G,
     output.reserve(total);
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
-  const unsigned grid = detail::grid_for(total, k::MP_TILE);
+  const unsigned grid = detail::grid_for(total, k::MP_TILE, (unsigned)context.compute_units() * 8u);
   unsigned long long* counters = context.workspace().counters();
   detail::clocked_t clock(context);
   if (holes)
@@ -372,7 +379,7 @@ void execute(graph_t& G,
   }
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
-  const unsigned grid = detail::grid_for(n_in, k::ADV_BLOCK);
+  const unsigned grid = detail::grid_for(n_in, k::ADV_BLOCK, (unsigned)context.compute_units() * 8u);
   unsigned long long* counters = context.workspace().counters();
   detail::clocked_t clock(context);
   if (holes)
@@ -427,7 +434,7 @@ void execute(graph_t& G,
   }
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
-  const unsigned grid = detail::grid_for(n_in, k::ADV_WAVES * 16);
+  const unsigned grid = detail::grid_for(n_in, k::ADV_WAVES, (unsigned)context.compute_units() * 8u);
   detail::clocked_t clock(context);
   k::wave_mapped_kernel<input_type, output_type><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
       G, op, input.data(), n_in, out_ptr, capacity, context.workspace().counters());
@@ -486,11 +493,14 @@ void execute(graph_t& G,
   vertex_t* medium_q = bins + n_in;
   unsigned long long* counters = ws.counters();
   const unsigned hub_threshold = context.options().hub_threshold;
+  const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
+  const unsigned persistent = (unsigned)context.compute_units() * 8u;
 
   detail::clocked_t clock(context);
   k::bucket_kernel<input_type><<<detail::grid_for(n_in, k::ADV_BLOCK, (unsigned)context.compute_units() * 8u),
                                  k::ADV_BLOCK, 0, context.stream()>>>(
-      G, input.data(), n_in, small_q, medium_q, chunks, chunk_capacity, hub_threshold, counters);
+      G, input.data(), n_in, small_q, medium_q, chunks, chunk_capacity, hub_threshold, chunk_edges,
+      counters);
   GRX_HIP_CHECK(hipGetLastError());
   unsigned long long* m = detail::fetch_counters(context);
   const std::size_t n_small = (std::size_t)m[k::C_BUCKET0];
@@ -501,11 +511,11 @@ void execute(graph_t& G,
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
   if (n_small)
     k::thread_mapped_kernel<false, vin, output_type>
-        <<<detail::grid_for(n_small, k::ADV_BLOCK), k::ADV_BLOCK, 0, context.stream()>>>(
+        <<<detail::grid_for(n_small, k::ADV_BLOCK, persistent), k::ADV_BLOCK, 0, context.stream()>>>(
             G, op, small_q, n_small, (const edge_t*)nullptr, out_ptr, capacity, counters);
   if (n_medium)
     k::wave_mapped_kernel<vin, output_type>
-        <<<detail::grid_for(n_medium, k::ADV_WAVES * 16), k::ADV_BLOCK, 0, context.stream()>>>(
+        <<<detail::grid_for(n_medium, k::ADV_WAVES, persistent), k::ADV_BLOCK, 0, context.stream()>>>(
             G, op, medium_q, n_medium, out_ptr, capacity, counters);
   if (n_chunks)
     k::chunk_kernel<output_type>

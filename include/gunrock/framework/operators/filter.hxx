@@ -75,9 +75,11 @@ void execute(graph_t&, operator_t op, frontier_t* input, frontier_t* output,
              gcuda::standard_context_t& context) {
   namespace k = ::gunrock::hip::kernels;
   const std::size_t n = input->get_number_of_elements();
+  const unsigned long long hint = input->work_hint();
   if (output->get_capacity() < n)
     output->reserve(n);
   output->set_number_of_elements(n);
+  output->set_work_hint(hint);  // elements are only removed: the bound still holds
   if (n) {
     std::size_t g = (n + k::CMP_BLOCK - 1) / k::CMP_BLOCK;
     const std::size_t cap = (std::size_t)context.compute_units() * 16;
@@ -107,8 +109,10 @@ void execute(graph_t&, operator_t op, frontier_t* input, frontier_t* output,
   auto keep = [op] __device__(std::size_t, type_t const& v) mutable -> bool {
     return util::limits::is_valid(v) ? op(v) : false;
   };
+  const unsigned long long hint = input->work_hint();
   output->set_number_of_elements(
       operators::detail::stable_select(input->data(), n, output->data(), keep, context));
+  output->set_work_hint(hint);
 }
 }  // namespace compact
 
@@ -205,11 +209,15 @@ void execute(frontier_t* input, frontier_t* output, gcuda::multi_context_t& cont
   auto first_of_run = [src] __device__(std::size_t i, type_t const& v) -> bool {
     return i == 0 || src[i - 1] != v;
   };
+  const unsigned long long hint = input->work_hint();
   const std::size_t m = operators::detail::stable_select(src, n, dst, first_of_run, ctx);
-  if (type == uniquify_algorithm_t::unique)
+  if (type == uniquify_algorithm_t::unique) {
     input->set_number_of_elements(m);
-  else
+    input->set_work_hint(hint);
+  } else {
     output->set_number_of_elements(m);
+    output->set_work_hint(hint);
+  }
 }
 
 /**

@@ -146,7 +146,9 @@ struct operator_options_t {
   /// false (default): only accepted neighbours are written, packed.
   bool holes_layout = false;
   /// Neighbour lists at least this long are cut into chunks spread over the GPU.
-  unsigned hub_threshold = 2048;
+  unsigned hub_threshold = 1024;
+  /// Edges per chunk of such a list (one persistent workgroup step).
+  unsigned chunk_edges = 1024;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };

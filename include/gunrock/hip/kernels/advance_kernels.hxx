@@ -13,16 +13,24 @@
  *    column_indices[e] for CONSECUTIVE e across the wavefront (coalesced 256-B
  *    requests out of HBM), never a private list unless the schedule is
  *    thread_mapped;
+ *  - workgroups are PERSISTENT (grid = a few per CU) and walk tiles / chunks /
+ *    edge ranges with a grid stride, so per-workgroup state survives across work
+ *    units;
  *  - the per-tile (vertex, first edge, scanned degree) triples live in LDS and
  *    the owner of edge i is found by binary search there;
  *  - accepted neighbours are packed with ballot + mbcnt into a PER-WAVEFRONT LDS
- *    queue whose fill level is a wave-uniform register: no LDS atomics, no
- *    workgroup barrier while expanding; a workgroup issues ONE global cursor
- *    atomic per tile (queues are drained together), so the single output cursor
- *    sees O(tiles) atomics instead of O(edges/64);
+ *    queue whose fill level is a wave-uniform register: no LDS atomics and no
+ *    workgroup barrier while expanding.  A wavefront claims output space with one
+ *    global atomic per ~450 accepted neighbours, a workgroup with one more when it
+ *    retires -- the single output cursor saturates near 90 atomics/us on MI355X,
+ *    so it must see O(outputs/450 + workgroups) atomics, not O(tiles);
  *  - lists of >= hub_threshold edges are not expanded in place: they are cut into
- *    fixed chunks appended to a device queue that a second, persistent kernel
- *    spreads over all 256 CUs (an RMAT-22 hub has 3e5 edges);
+ *    fixed chunks appended to a device queue (one reservation atomic per tile)
+ *    that a second persistent kernel spreads over all 256 CUs (an RMAT-22 hub has
+ *    3e5 edges);
+ *  - while packing, the kernel also sums the degrees of the neighbours it emits:
+ *    the next advance over that frontier then knows an upper bound of its work
+ *    without the reference's extra reduction pass (advance/helpers.hxx:112-146);
  *  - "holes" layout (one output slot per traversed edge, invalid where the op
  *    said no) reproduces the reference's output exactly and is kept as a mode;
  *    the default "packed" layout writes only accepted neighbours.
@@ -41,12 +49,10 @@ namespace kernels {
 
 using operators::advance_io_type_t;
 
-constexpr int ADV_BLOCK = 256;                        // threads per workgroup
-constexpr int ADV_WAVES = ADV_BLOCK / wave_size;      // 4
-constexpr int ADV_WQCAP = 512;                        // entries of one wavefront's output queue
-constexpr int ADV_UNROLL = 4;                         // independent edges in flight per lane
-constexpr int ADV_CHUNK = 2048;                       // edges per hub chunk
-constexpr int ADV_HUB_THRESHOLD = ADV_CHUNK;          // lists this long are chunked
+constexpr int ADV_BLOCK = 256;                    // threads per workgroup
+constexpr int ADV_WAVES = ADV_BLOCK / wave_size;  // 4
+constexpr int ADV_WQCAP = 512;                    // entries of one wavefront's output queue
+constexpr int ADV_UNROLL = 4;                     // independent edges in flight per lane
 
 enum counter_slot : int {
   C_OUT = 0,        ///< output cursor (elements)
@@ -54,7 +60,8 @@ enum counter_slot : int {
   C_WORK = 2,       ///< degree sum / total work of the input frontier
   C_OVERFLOW = 3,   ///< set when an output write was dropped for lack of capacity
   C_TILE = 4,       ///< dynamic tile cursor (work_stealing)
-  C_BUCKET0 = 8,    ///< bucketing: small / medium / large queue cursors (8,9,10)
+  C_NEXT_WORK = 5,  ///< sum of degrees of the emitted neighbours (work of the next advance)
+  C_BUCKET0 = 8,    ///< bucketing: small / medium queue cursors (8, 9)
   C_MAXDEG = 12,    ///< max degree reduction
   C_SELECT = 16     ///< compaction: number of selected elements
 };
@@ -66,39 +73,14 @@ struct chunk_t {
   edge_t first;
 };
 
-
-/**
- * @brief Cut a long neighbour list into ADV_CHUNK-edge descriptors appended to
- * the device chunk queue.  Returns false (nothing usable written) when the queue
- * cannot take the whole list; the part of the reservation that does fit is then
- * filled with empty descriptors so the consumer never reads unwritten entries.
- */
-template <typename vertex_t, typename edge_t>
-__device__ __forceinline__ bool spill_hub(vertex_t v, edge_t first, unsigned deg,
-                                          chunk_t<vertex_t, edge_t>* chunks,
-                                          unsigned long long chunk_capacity,
-                                          unsigned long long* counters) {
-  const unsigned n_chunks = (deg + ADV_CHUNK - 1) / ADV_CHUNK;
-  const unsigned long long at = atomicAdd(&counters[C_CHUNKS], (unsigned long long)n_chunks);
-  const bool fits = at + n_chunks <= chunk_capacity;
-  for (unsigned c = 0; c < n_chunks && at + c < chunk_capacity; ++c) {
-    const unsigned off = c * ADV_CHUNK;
-    chunk_t<vertex_t, edge_t> d;
-    d.source = v;
-    d.first = first + (edge_t)off;
-    d.count = fits ? (int)((deg - off < (unsigned)ADV_CHUNK) ? deg - off : (unsigned)ADV_CHUNK) : 0;
-    chunks[at + c] = d;
-  }
-  return fits;
-}
-
 // ---------------------------------------------------------------------------
 // Per-wavefront output queue (LDS), fill level in a wave-uniform register.
 // ---------------------------------------------------------------------------
 template <typename vertex_t>
 struct wave_queue_t {
-  vertex_t* q;     // this wavefront's ADV_WQCAP entries in LDS
-  unsigned fill;   // wave-uniform
+  vertex_t* q;              // this wavefront's ADV_WQCAP entries in LDS
+  unsigned fill;            // wave-uniform
+  unsigned long long work;  // per lane: sum of degrees of the neighbours this lane emitted
 
   __device__ __forceinline__ void flush(vertex_t* out, std::size_t capacity,
                                         unsigned long long* counters) {
@@ -119,28 +101,35 @@ struct wave_queue_t {
   }
 
   /// All 64 lanes must call (keep=false for idle lanes).
-  __device__ __forceinline__ void push(bool keep, vertex_t value, vertex_t* out,
+  __device__ __forceinline__ void push(bool keep, vertex_t value, unsigned degree, vertex_t* out,
                                        std::size_t capacity, unsigned long long* counters) {
     unsigned long long m = __ballot(keep);
     if (m == 0)
       return;
     if (fill + wave_size > (unsigned)ADV_WQCAP)
       flush(out, capacity, counters);
-    if (keep)
+    if (keep) {
       q[fill + rank_in_mask(m)] = value;
+      work += degree;
+    }
     fill += (unsigned)__popcll(m);
   }
 };
 
-/// Drain the four wavefront queues of a workgroup with ONE global atomic.
+/// Retire a workgroup: drain its four wavefront queues with ONE cursor atomic and
+/// publish the degree sum of everything it emitted.  Contains barriers.
 template <typename vertex_t>
 __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned* s_counts,
                                             unsigned long long* s_base, vertex_t* out,
                                             std::size_t capacity, unsigned long long* counters) {
   const int lane = lane_id();
   const int wave = threadIdx.x / wave_size;
-  if (lane == 0)
+  const unsigned long long wave_work = wave_sum(wq.work);
+  if (lane == 0) {
     s_counts[wave] = wq.fill;
+    if (wave_work)
+      atomicAdd(&counters[C_NEXT_WORK], wave_work);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned total = 0;
@@ -160,18 +149,21 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
       counters[C_OVERFLOW] = 1ull;
   }
   wq.fill = 0;
-  __syncthreads();  // s_counts / s_base are reused by the next tile
+  wq.work = 0;
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
 // Sum / max of degrees of the valid input slots.
 // Restates advance/helpers.hxx:112-146 (compute_output_length) as one kernel with
-// a 64-bit result (the reference sums in edge_t, SURVEY.md 8a' q8).
+// a 64-bit result (the reference sums in edge_t, SURVEY.md 8a' q8).  One atomic
+// per workgroup; launch with a few hundred workgroups.
 // ---------------------------------------------------------------------------
 template <advance_io_type_t IN, typename graph_t, typename vertex_t>
 __global__ void __launch_bounds__(ADV_BLOCK)
     degree_sum_kernel(graph_t G, const vertex_t* input, std::size_t n_in,
                       unsigned long long* counters) {
+  __shared__ unsigned long long s_part[ADV_WAVES];
   unsigned long long local = 0;
   for (std::size_t i = blockIdx.x * (std::size_t)ADV_BLOCK + threadIdx.x; i < n_in;
        i += (std::size_t)gridDim.x * ADV_BLOCK) {
@@ -180,14 +172,24 @@ __global__ void __launch_bounds__(ADV_BLOCK)
       local += (unsigned long long)G.get_number_of_neighbors(v);
   }
   local = wave_sum(local);
-  if (lane_id() == 0 && local)
-    atomicAdd(&counters[C_WORK], local);
+  if (lane_id() == 0)
+    s_part[threadIdx.x / wave_size] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < ADV_WAVES; ++w)
+      t += s_part[w];
+    if (t)
+      atomicAdd(&counters[C_WORK], t);
+  }
 }
 
 template <typename graph_t>
 __global__ void __launch_bounds__(ADV_BLOCK)
     max_degree_kernel(graph_t G, unsigned long long* counters) {
   using vertex_t = typename graph_t::vertex_type;
+  __shared__ unsigned long long s_part[ADV_WAVES];
   unsigned long long local = 0;
   const std::size_t n = (std::size_t)G.get_number_of_vertices();
   for (std::size_t i = blockIdx.x * (std::size_t)ADV_BLOCK + threadIdx.x; i < n;
@@ -196,12 +198,21 @@ __global__ void __launch_bounds__(ADV_BLOCK)
     local = d > local ? d : local;
   }
   local = wave_max(local);
-  if (lane_id() == 0 && local)
-    atomicMax(&counters[C_MAXDEG], local);
+  if (lane_id() == 0)
+    s_part[threadIdx.x / wave_size] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < ADV_WAVES; ++w)
+      t = s_part[w] > t ? s_part[w] : t;
+    if (t)
+      atomicMax(&counters[C_MAXDEG], t);
+  }
 }
 
 // ---------------------------------------------------------------------------
-// block_mapped: one workgroup per tile of ADV_BLOCK input slots.
+// block_mapped: persistent workgroups over tiles of ADV_BLOCK input slots.
 // ---------------------------------------------------------------------------
 template <bool HOLES,
           bool DYNAMIC,
@@ -221,22 +232,24 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                         unsigned long long* counters,
                         chunk_t<vertex_t, edge_t>* chunks,
                         unsigned long long chunk_capacity,
-                        unsigned hub_threshold) {
+                        unsigned hub_threshold,
+                        unsigned chunk_edges) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  constexpr bool PACKED = HAS_OUT && !HOLES;
 
   __shared__ vertex_t s_vertex[ADV_BLOCK];
   __shared__ edge_t s_first[ADV_BLOCK];
   __shared__ unsigned s_scan[ADV_BLOCK];
-  __shared__ unsigned s_wave_totals[ADV_WAVES + 1];
+  __shared__ unsigned long long s_wave_totals[ADV_WAVES + 1];
   __shared__ unsigned s_counts[ADV_WAVES];
   __shared__ unsigned long long s_base;
   __shared__ unsigned long long s_tile;
-  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+  __shared__ vertex_t s_queue[PACKED ? ADV_WAVES * ADV_WQCAP : 1];
 
   const int tid = threadIdx.x;
   const int wave = tid / wave_size;
-  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? wave * ADV_WQCAP : 0), 0u};
+  wave_queue_t<vertex_t> wq{s_queue + (PACKED ? wave * ADV_WQCAP : 0), 0u, 0ull};
 
   const unsigned long long n_tiles = (n_in + ADV_BLOCK - 1) / ADV_BLOCK;
   unsigned long long tile = blockIdx.x;
@@ -260,16 +273,49 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         deg = (unsigned)(G.get_starting_edge(v + 1) - first);
       }
     }
-    // ---- 2. hubs leave the tile as equal chunks -----------------------------
-    if (!HOLES && deg >= hub_threshold) {
-      if (spill_hub(v, first, deg, chunks, chunk_capacity, counters))
-        deg = 0;
-      // else: the queue is full; this list is expanded in place (slow, correct)
+    // ---- 2. hubs leave the tile as equal chunks; one reservation per tile ----
+    //         (degree, chunk count) are scanned together, packed in 64 bits
+    unsigned my_chunks = 0;
+    if (!HOLES && deg >= hub_threshold)
+      my_chunks = (deg + chunk_edges - 1) / chunk_edges;
+    unsigned long long packed = ((unsigned long long)my_chunks << 32) | (my_chunks ? 0u : deg);
+    unsigned long long packed_total;
+    unsigned long long packed_excl =
+        block_exclusive_sum<ADV_BLOCK>(packed, packed_total, s_wave_totals);
+    unsigned total = (unsigned)packed_total;
+    unsigned excl = (unsigned)packed_excl;
+    if (!HOLES) {
+      const unsigned tile_chunks = (unsigned)(packed_total >> 32);
+      if (tile_chunks) {  // workgroup-uniform
+        if (tid == 0)
+          s_base = atomicAdd(&counters[C_CHUNKS], (unsigned long long)tile_chunks);
+        __syncthreads();
+        const unsigned long long at = s_base + (packed_excl >> 32);
+        const bool fits = s_base + tile_chunks <= chunk_capacity;
+        if (my_chunks) {
+          for (unsigned c = 0; c < my_chunks && at + c < chunk_capacity; ++c) {
+            const unsigned off = c * chunk_edges;
+            chunk_t<vertex_t, edge_t> d;
+            d.source = v;
+            d.first = first + (edge_t)off;
+            d.count = fits ? (int)((deg - off < chunk_edges) ? deg - off : chunk_edges) : 0;
+            chunks[at + c] = d;
+          }
+        }
+        __syncthreads();  // s_base is reused below
+        if (!fits) {
+          // the queue is full: this tile expands its hubs in place (slow, correct)
+          unsigned t2;
+          unsigned long long p2 = block_exclusive_sum<ADV_BLOCK>((unsigned long long)deg,
+                                                                 packed_total, s_wave_totals);
+          t2 = (unsigned)packed_total;
+          total = t2;
+          excl = (unsigned)p2;
+        }
+      }
     }
     s_vertex[tid] = v;
     s_first[tid] = first;
-    unsigned total;
-    const unsigned excl = block_exclusive_sum<ADV_BLOCK>(deg, total, s_wave_totals);
     s_scan[tid] = excl;
     if (HOLES && HAS_OUT && tid == 0)
       s_base = total ? atomicAdd(&counters[C_OUT], (unsigned long long)total) : 0ull;
@@ -308,17 +354,15 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                 counters[C_OVERFLOW] = 1ull;
             }
           } else {
-            wq.push(keep, nbr[k], output, capacity, counters);
+            unsigned dn = 0;
+            if (keep)
+              dn = (unsigned)G.get_number_of_neighbors(nbr[k]);
+            wq.push(keep, nbr[k], dn, output, capacity, counters);
           }
         }
       }
     }
-
-    // ---- 4. one cursor atomic per tile --------------------------------------
-    if constexpr (HAS_OUT && !HOLES)
-      drain_block(wq, s_counts, &s_base, output, capacity, counters);
-    else
-      __syncthreads();  // LDS tile arrays are rewritten by the next tile
+    __syncthreads();  // the LDS tile arrays are rewritten by the next tile
 
     if (DYNAMIC) {
       if (tid == 0)
@@ -329,11 +373,13 @@ __global__ void __launch_bounds__(ADV_BLOCK)
       tile += gridDim.x;
     }
   }
+  if constexpr (PACKED)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
 }
 
 // ---------------------------------------------------------------------------
-// Hub chunks: persistent workgroups, one chunk (<= ADV_CHUNK consecutive edges of
-// one source) at a time, lanes on consecutive edges.
+// Hub chunks: persistent workgroups, one chunk (consecutive edges of one source)
+// at a time, lanes on consecutive edges.
 // ---------------------------------------------------------------------------
 template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t, typename edge_t>
 __global__ void __launch_bounds__(ADV_BLOCK)
@@ -351,7 +397,7 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
 
   const int tid = threadIdx.x;
-  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
 
   unsigned long long n_chunks = counters[C_CHUNKS];
   if (n_chunks > chunk_capacity)
@@ -380,13 +426,17 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         bool keep = false;
         if (live[k])
           keep = op(source, nbr[k], eid[k], wgt[k]);
-        if constexpr (HAS_OUT)
-          wq.push(keep, nbr[k], output, capacity, counters);
+        if constexpr (HAS_OUT) {
+          unsigned dn = 0;
+          if (keep)
+            dn = (unsigned)G.get_number_of_neighbors(nbr[k]);
+          wq.push(keep, nbr[k], dn, output, capacity, counters);
+        }
       }
     }
-    if constexpr (HAS_OUT)
-      drain_block(wq, s_counts, &s_base, output, capacity, counters);
   }
+  if constexpr (HAS_OUT)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -411,45 +461,53 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                          unsigned long long* counters) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  constexpr bool PACKED = HAS_OUT && !HOLES;
   __shared__ unsigned s_counts[ADV_WAVES];
   __shared__ unsigned long long s_base;
-  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+  __shared__ vertex_t s_queue[PACKED ? ADV_WAVES * ADV_WQCAP : 1];
   const int tid = threadIdx.x;
-  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+  wave_queue_t<vertex_t> wq{s_queue + (PACKED ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
 
-  const std::size_t idx = blockIdx.x * (std::size_t)ADV_BLOCK + tid;
-  vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
-  edge_t first = 0;
-  edge_t deg = 0;
-  if (idx < n_in) {
-    v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
-    if (util::limits::is_valid(v)) {
-      first = G.get_starting_edge(v);
-      deg = G.get_starting_edge(v + 1) - first;
-    }
-  }
-  // the wavefront iterates to its longest list; shorter lanes idle
-  const edge_t longest = wave_max(deg);
-  for (edge_t r = 0; r < longest; ++r) {
-    bool keep = false;
-    vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
-    if (r < deg) {
-      edge_t e = first + r;
-      n = G.get_destination_vertex(e);
-      weight_t w = G.get_edge_weight(e);
-      keep = op(v, n, e, w);
-      if constexpr (HAS_OUT && HOLES) {
-        const unsigned long long at = (unsigned long long)segments[idx] + (unsigned long long)r;
-        if (at < capacity)
-          output[at] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
-        else
-          counters[C_OVERFLOW] = 1ull;
+  const std::size_t n_tiles = (n_in + ADV_BLOCK - 1) / ADV_BLOCK;
+  for (std::size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const std::size_t idx = tile * ADV_BLOCK + tid;
+    vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
+    edge_t first = 0;
+    edge_t deg = 0;
+    if (idx < n_in) {
+      v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      if (util::limits::is_valid(v)) {
+        first = G.get_starting_edge(v);
+        deg = G.get_starting_edge(v + 1) - first;
       }
     }
-    if constexpr (HAS_OUT && !HOLES)
-      wq.push(keep, n, output, capacity, counters);
+    // the wavefront iterates to its longest list; shorter lanes idle
+    const edge_t longest = wave_max(deg);
+    for (edge_t r = 0; r < longest; ++r) {
+      bool keep = false;
+      vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
+      if (r < deg) {
+        edge_t e = first + r;
+        n = G.get_destination_vertex(e);
+        weight_t w = G.get_edge_weight(e);
+        keep = op(v, n, e, w);
+        if constexpr (HAS_OUT && HOLES) {
+          const unsigned long long at = (unsigned long long)segments[idx] + (unsigned long long)r;
+          if (at < capacity)
+            output[at] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
+          else
+            counters[C_OVERFLOW] = 1ull;
+        }
+      }
+      if constexpr (PACKED) {
+        unsigned dn = 0;
+        if (keep)
+          dn = (unsigned)G.get_number_of_neighbors(n);
+        wq.push(keep, n, dn, output, capacity, counters);
+      }
+    }
   }
-  if constexpr (HAS_OUT && !HOLES)
+  if constexpr (PACKED)
     drain_block(wq, s_counts, &s_base, output, capacity, counters);
 }
 
@@ -478,18 +536,14 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid / wave_size;
-  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u};
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
 
-  // a workgroup takes 4 * SLOTS_PER_WAVE consecutive slots, a wavefront SLOTS_PER_WAVE of them
-  constexpr int SLOTS_PER_WAVE = 16;
-  const std::size_t base_slot = ((std::size_t)blockIdx.x * ADV_WAVES + wave) * SLOTS_PER_WAVE;
-  for (int s = 0; s < SLOTS_PER_WAVE; ++s) {
-    const std::size_t idx = base_slot + s;
-    if (idx >= n_in)
-      break;  // wave-uniform
+  // wavefront w of the grid takes slots w, w + W, w + 2W, ...
+  const std::size_t n_waves = (std::size_t)gridDim.x * ADV_WAVES;
+  for (std::size_t idx = (std::size_t)blockIdx.x * ADV_WAVES + wave; idx < n_in; idx += n_waves) {
     vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
     if (!util::limits::is_valid(v))
-      continue;
+      continue;  // wave-uniform
     const edge_t first = G.get_starting_edge(v);
     const edge_t deg = G.get_starting_edge(v + 1) - first;
     for (edge_t r0 = 0; r0 < deg; r0 += wave_size) {
@@ -502,8 +556,12 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         weight_t w = G.get_edge_weight(e);
         keep = op(v, n, e, w);
       }
-      if constexpr (HAS_OUT)
-        wq.push(keep, n, output, capacity, counters);
+      if constexpr (HAS_OUT) {
+        unsigned dn = 0;
+        if (keep)
+          dn = (unsigned)G.get_number_of_neighbors(n);
+        wq.push(keep, n, dn, output, capacity, counters);
+      }
     }
   }
   if constexpr (HAS_OUT)
@@ -512,14 +570,14 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 
 // ---------------------------------------------------------------------------
 // merge_path: segments[] = exclusive scan of the input slots' degrees
-// (segments[n_in] = total).  Every workgroup owns MP_TILE consecutive WORK ITEMS
-// (edges), finds the slots that overlap them, stages those in LDS and expands.
-// Output position in holes mode is the work-item index itself (deterministic,
-// like reference merge_path.hxx:104-105).
+// (segments[n_in] = total).  Persistent workgroups take MP_TILE consecutive WORK
+// ITEMS (edges) at a time, find the slots that overlap them, stage those in LDS
+// and expand.  Output position in holes mode is the work-item index itself
+// (deterministic, like reference merge_path.hxx:104-105).
 // ---------------------------------------------------------------------------
 constexpr int MP_EPT = 4;
-constexpr int MP_TILE = ADV_BLOCK * MP_EPT;  // 1024 edges per workgroup
-constexpr int MP_SLOTS = 1024;               // slots staged in LDS per workgroup
+constexpr int MP_TILE = ADV_BLOCK * MP_EPT;  // 1024 edges per step
+constexpr int MP_SLOTS = 1024;               // slots staged in LDS per step
 
 template <typename edge_t>
 __device__ __forceinline__ std::size_t global_rightmost_le(const edge_t* seg, std::size_t n,
@@ -555,67 +613,74 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                       unsigned long long* counters) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  constexpr bool PACKED = HAS_OUT && !HOLES;
   __shared__ vertex_t s_vertex[MP_SLOTS];
   __shared__ edge_t s_first[MP_SLOTS];
   __shared__ edge_t s_seg[MP_SLOTS];
   __shared__ unsigned s_counts[ADV_WAVES];
   __shared__ unsigned long long s_base;
-  __shared__ vertex_t s_queue[(HAS_OUT && !HOLES) ? ADV_WAVES * ADV_WQCAP : 1];
+  __shared__ vertex_t s_queue[PACKED ? ADV_WAVES * ADV_WQCAP : 1];
   const int tid = threadIdx.x;
-  wave_queue_t<vertex_t> wq{s_queue + ((HAS_OUT && !HOLES) ? (tid / wave_size) * ADV_WQCAP : 0), 0u};
+  wave_queue_t<vertex_t> wq{s_queue + (PACKED ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
 
-  const unsigned long long w0 = (unsigned long long)blockIdx.x * MP_TILE;
-  if (w0 >= total_work)
-    return;
-  const unsigned long long w1 = (w0 + MP_TILE < total_work) ? w0 + MP_TILE : total_work;
+  const unsigned long long n_steps = (total_work + MP_TILE - 1) / MP_TILE;
+  for (unsigned long long step = blockIdx.x; step < n_steps; step += gridDim.x) {
+    const unsigned long long w0 = step * MP_TILE;
+    const unsigned long long w1 = (w0 + MP_TILE < total_work) ? w0 + MP_TILE : total_work;
 
-  // slots overlapping [w0, w1): every lane runs the same two searches (broadcast loads)
-  const std::size_t slot_lo = global_rightmost_le(segments, n_in, w0);
-  const std::size_t slot_hi = global_rightmost_le(segments, n_in, w1 - 1);
-  const std::size_t n_slots = slot_hi - slot_lo + 1;
-  const bool staged = n_slots <= (std::size_t)MP_SLOTS;
-  if (staged) {
-    for (std::size_t s = tid; s < n_slots; s += ADV_BLOCK) {
-      const std::size_t idx = slot_lo + s;
-      vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
-      s_vertex[s] = v;
-      s_seg[s] = segments[idx];
-      s_first[s] = util::limits::is_valid(v) ? G.get_starting_edge(v) : (edge_t)0;
+    // slots overlapping [w0, w1): every lane runs the same two searches (broadcast loads)
+    const std::size_t slot_lo = global_rightmost_le(segments, n_in, w0);
+    const std::size_t slot_hi = global_rightmost_le(segments, n_in, w1 - 1);
+    const std::size_t n_slots = slot_hi - slot_lo + 1;
+    const bool staged = n_slots <= (std::size_t)MP_SLOTS;
+    if (staged) {
+      for (std::size_t s = tid; s < n_slots; s += ADV_BLOCK) {
+        const std::size_t idx = slot_lo + s;
+        vertex_t v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+        s_vertex[s] = v;
+        s_seg[s] = segments[idx];
+        s_first[s] = util::limits::is_valid(v) ? G.get_starting_edge(v) : (edge_t)0;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
 #pragma unroll
-  for (int k = 0; k < MP_EPT; ++k) {
-    const unsigned long long i = w0 + (unsigned long long)k * ADV_BLOCK + tid;
-    bool keep = false;
-    vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
-    if (i < w1) {
-      vertex_t v;
-      edge_t e;
-      if (staged) {
-        const int s = rightmost_le(s_seg, (edge_t)i, (int)n_slots);
-        v = s_vertex[s];
-        e = s_first[s] + ((edge_t)i - s_seg[s]);
-      } else {
-        const std::size_t idx = slot_lo + global_rightmost_le(segments + slot_lo, n_slots, i);
-        v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
-        e = G.get_starting_edge(v) + ((edge_t)i - segments[idx]);
+    for (int k = 0; k < MP_EPT; ++k) {
+      const unsigned long long i = w0 + (unsigned long long)k * ADV_BLOCK + tid;
+      bool keep = false;
+      vertex_t n = gunrock::numeric_limits<vertex_t>::invalid();
+      if (i < w1) {
+        vertex_t v;
+        edge_t e;
+        if (staged) {
+          const int s = rightmost_le(s_seg, (edge_t)i, (int)n_slots);
+          v = s_vertex[s];
+          e = s_first[s] + ((edge_t)i - s_seg[s]);
+        } else {
+          const std::size_t idx = slot_lo + global_rightmost_le(segments + slot_lo, n_slots, i);
+          v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+          e = G.get_starting_edge(v) + ((edge_t)i - segments[idx]);
+        }
+        n = G.get_destination_vertex(e);
+        weight_t w = G.get_edge_weight(e);
+        keep = op(v, n, e, w);
+        if constexpr (HAS_OUT && HOLES) {
+          if (i < capacity)
+            output[i] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
+          else
+            counters[C_OVERFLOW] = 1ull;
+        }
       }
-      n = G.get_destination_vertex(e);
-      weight_t w = G.get_edge_weight(e);
-      keep = op(v, n, e, w);
-      if constexpr (HAS_OUT && HOLES) {
-        if (i < capacity)
-          output[i] = keep ? n : gunrock::numeric_limits<vertex_t>::invalid();
-        else
-          counters[C_OVERFLOW] = 1ull;
+      if constexpr (PACKED) {
+        unsigned dn = 0;
+        if (keep)
+          dn = (unsigned)G.get_number_of_neighbors(n);
+        wq.push(keep, n, dn, output, capacity, counters);
       }
     }
-    if constexpr (HAS_OUT && !HOLES)
-      wq.push(keep, n, output, capacity, counters);
+    __syncthreads();  // LDS staging arrays are rewritten by the next step
   }
-  if constexpr (HAS_OUT && !HOLES)
+  if constexpr (PACKED)
     drain_block(wq, s_counts, &s_base, output, capacity, counters);
 }
 
@@ -637,7 +702,7 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 
 // ---------------------------------------------------------------------------
 // bucketing: bin valid input slots by degree into three queues.
-//   small  (< 16)            -> thread-per-slot        (thread_mapped_kernel)
+//   small  (< BUCKET_SMALL)  -> thread-per-slot        (thread_mapped_kernel)
 //   medium (< hub_threshold) -> wavefront-per-slot     (wave_mapped_kernel)
 //   large                    -> equal chunks           (chunk_kernel)
 // Davidson et al.'s SSSP schedule, which the reference names but leaves empty
@@ -655,9 +720,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                   chunk_t<vertex_t, edge_t>* chunks,
                   unsigned long long chunk_capacity,
                   unsigned hub_threshold,
+                  unsigned chunk_edges,
                   unsigned long long* counters) {
-  __shared__ unsigned s_counts[ADV_WAVES];
-  __shared__ unsigned long long s_base;
   // two wavefront queues: small and medium ids
   __shared__ vertex_t s_small[ADV_WAVES * ADV_WQCAP];
   __shared__ vertex_t s_medium[ADV_WAVES * ADV_WQCAP];
@@ -696,8 +760,26 @@ __global__ void __launch_bounds__(ADV_BLOCK)
     }
     const bool is_small = deg > 0 && deg < BUCKET_SMALL;
     bool is_medium = deg >= BUCKET_SMALL && deg < hub_threshold;
-    if (deg >= hub_threshold) {
-      if (!spill_hub(v, first, deg, chunks, chunk_capacity, counters))
+    // large lists: wave-aggregated chunk reservation
+    const unsigned my_chunks = (deg >= hub_threshold) ? (deg + chunk_edges - 1) / chunk_edges : 0u;
+    const unsigned incl = wave_inclusive_sum(my_chunks);
+    const unsigned wave_chunks = __shfl(incl, wave_size - 1, wave_size);
+    if (wave_chunks) {  // wave-uniform
+      unsigned long long base = 0;
+      if (lane == 0)
+        base = atomicAdd(&counters[C_CHUNKS], (unsigned long long)wave_chunks);
+      base = __shfl(base, 0, wave_size);
+      const bool fits = base + wave_chunks <= chunk_capacity;
+      const unsigned long long at = base + (incl - my_chunks);
+      for (unsigned c = 0; c < my_chunks && at + c < chunk_capacity; ++c) {
+        const unsigned off = c * chunk_edges;
+        chunk_t<vertex_t, edge_t> d;
+        d.source = v;
+        d.first = first + (edge_t)off;
+        d.count = fits ? (int)((deg - off < chunk_edges) ? deg - off : chunk_edges) : 0;
+        chunks[at + c] = d;
+      }
+      if (!fits && my_chunks)
         is_medium = true;  // queue full: a wavefront walks it
     }
     unsigned long long ms = __ballot(is_small);
@@ -719,8 +801,6 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   }
   flush(qs, n_small, small_q, C_BUCKET0);
   flush(qm, n_medium, medium_q, C_BUCKET0 + 1);
-  (void)s_counts;
-  (void)s_base;
 }
 
 }  // namespace kernels

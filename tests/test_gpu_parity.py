@@ -188,8 +188,9 @@ def test_advance_matches_oracle(ea, ctx, torch, oracle, lb, holes):
         for f in _frontier_cases(n, rng):
             calls = torch.zeros(max(len(Aj), 1), dtype=torch.int32, device="cuda")
             ft = torch.from_numpy(f).cuda()
+            work = int(np.diff(Ap)[f[f != -1]].sum()) if len(f) else 0
             out = ea.advance(ctx, G, ft, ea.EdgeOp.count_edge, calls, 0, opts,
-                             capacity=max(16, 4 * len(Aj) + 16))
+                             capacity=work + 16)
             want_calls = np.zeros(max(len(Aj), 1), np.int64)
 
             def op(s, d, e, w):
