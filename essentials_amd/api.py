@@ -16,7 +16,8 @@ from typing import Optional
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG, "libessentials_amd.so")
+# ESSENTIALS_AMD_LIB selects an experiment build of the SAME library (see build.build_variant)
+_LIB_PATH = os.environ.get("ESSENTIALS_AMD_LIB") or os.path.join(_PKG, "libessentials_amd.so")
 
 INT_UNREACHED = 2**31 - 1
 FLT_UNREACHED = float(np.finfo(np.float32).max)

@@ -39,12 +39,32 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths) if paths else 0.0
 
 
-def _compile(src, obj):
-    cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+def _compile(src, obj, defines=()):
+    cmd = [HIPCC, "-x", "hip"] + FLAGS + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {os.path.basename(src)}:\n{r.stderr[-6000:]}")
     return obj
+
+
+def build_variant(name: str, defines, only=None, jobs: int | None = None) -> str:
+    """Experiment build: essentials_amd/libessentials_amd.<name>.so with extra -D flags
+    (loaded when ESSENTIALS_AMD_LIB points at it).  Not part of the product build."""
+    objdir = os.path.join(OBJ, name)
+    os.makedirs(objdir, exist_ok=True)
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    todo, objs = [], []
+    for s in sources:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        todo.append((s, o))
+    with ThreadPoolExecutor(jobs or 8) as ex:
+        list(ex.map(lambda so: _compile(so[0], so[1], defines), todo))
+    lib = os.path.join(PKG, f"libessentials_amd.{name}.so")
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + \
+          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return lib
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
@@ -78,9 +98,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--variant", default=None, help="experiment build name")
+    ap.add_argument("-D", dest="defines", action="append", default=[])
     a = ap.parse_args()
     try:
-        print(build(a.force, a.jobs, verbose=True))
+        if a.variant:
+            print(build_variant(a.variant, a.defines, jobs=a.jobs))
+        else:
+            print(build(a.force, a.jobs, verbose=True))
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

@@ -153,12 +153,22 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
     output.set_work_hint(m[k::C_NEXT_WORK]);
 }
 
-/// Device chunk queue sized for every hub of the graph at once.
+/// Device chunk queue sized for every hub of this call: a list of d edges makes at most
+/// d / chunk_edges + 1 chunks, and only lists of >= hub_threshold edges make any.
 template <typename vertex_t, typename edge_t, typename graph_t>
-k::chunk_t<vertex_t, edge_t>* chunk_queue(graph_t& G, unsigned long long& capacity,
+k::chunk_t<vertex_t, edge_t>* chunk_queue(graph_t& G, std::size_t n_in, unsigned long long work_bound,
+                                          unsigned long long& capacity,
                                           gcuda::standard_context_t& ctx) {
   const unsigned chunk_edges = ctx.options().chunk_edges ? ctx.options().chunk_edges : 1024u;
-  capacity = (unsigned long long)G.get_number_of_edges() / chunk_edges + 65536;
+  const unsigned hub = ctx.options().hub_threshold ? ctx.options().hub_threshold : 1u;
+  unsigned long long hubs = n_in;
+  if (work_bound != ~0ull) {
+    if (work_bound / hub < hubs)
+      hubs = work_bound / hub;
+  } else {
+    work_bound = (unsigned long long)G.get_number_of_edges() + (unsigned long long)n_in * hub;
+  }
+  capacity = work_bound / chunk_edges + hubs + 1024;
   return reinterpret_cast<k::chunk_t<vertex_t, edge_t>*>(
       ctx.workspace().queue(capacity * sizeof(k::chunk_t<vertex_t, edge_t>)));
 }
@@ -205,12 +215,16 @@ void execute(graph_t& G,
   }
 
   unsigned long long chunk_capacity = 0;
-  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, chunk_capacity, context);
+  unsigned long long work_bound = total;
+  if (work_bound == ~0ull)
+    work_bound = (input_type == advance_io_type_t::graph) ? (unsigned long long)G.get_number_of_edges()
+                                                          : input.work_hint();
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, n_in, work_bound, chunk_capacity, context);
   const unsigned hub_threshold = context.options().hub_threshold;
   const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
   unsigned long long* counters = context.workspace().counters();
   const std::size_t n_tiles = (n_in + k::ADV_BLOCK - 1) / k::ADV_BLOCK;
-  const unsigned persistent = (unsigned)context.compute_units() * 8u;
+  const unsigned persistent = (unsigned)context.compute_units() * context.options().tile_blocks_per_cu;
   const unsigned grid = (unsigned)(n_tiles < persistent ? n_tiles : persistent);
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
@@ -227,9 +241,9 @@ void execute(graph_t& G,
                                                       counters, chunks, chunk_capacity,
                                                       hub_threshold, chunk_edges);
     if (max_deg >= hub_threshold) {
-      k::chunk_kernel<output_type><<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0,
-                                     context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr,
-                                                         capacity, counters);
+      k::chunk_kernel<output_type>
+          <<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu, k::ADV_BLOCK,
+             0, context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
     }
   }
   GRX_HIP_CHECK(hipGetLastError());
@@ -487,7 +501,11 @@ void execute(graph_t& G,
   }
   auto& ws = context.workspace();
   unsigned long long chunk_capacity = 0;
-  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, chunk_capacity, context);
+  unsigned long long work_bound = total;
+  if (work_bound == ~0ull)
+    work_bound = (input_type == advance_io_type_t::graph) ? (unsigned long long)G.get_number_of_edges()
+                                                          : input.work_hint();
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, n_in, work_bound, chunk_capacity, context);
   vertex_t* bins = reinterpret_cast<vertex_t*>(ws.scratch(2 * n_in * sizeof(vertex_t)));
   vertex_t* small_q = bins;
   vertex_t* medium_q = bins + n_in;
@@ -519,8 +537,8 @@ void execute(graph_t& G,
             G, op, medium_q, n_medium, out_ptr, capacity, counters);
   if (n_chunks)
     k::chunk_kernel<output_type>
-        <<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0, context.stream()>>>(
-            G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
+        <<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu, k::ADV_BLOCK, 0,
+           context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
   GRX_HIP_CHECK(hipGetLastError());
   clock.stop();
   if (has_out)

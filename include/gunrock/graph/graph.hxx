@@ -85,10 +85,18 @@ class graph_csr_t {
     return offsets[v + 1] - offsets[v];
   }
   __host__ __device__ __forceinline__ vertex_t get_destination_vertex(edge_t const& e) const {
+#if defined(GRX_STREAM_NT) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(&indices[e]);
+#else
     return indices[e];
+#endif
   }
   __host__ __device__ __forceinline__ weight_t get_edge_weight(edge_t const& e) const {
+#if defined(GRX_STREAM_NT) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(&values[e]);
+#else
     return values[e];
+#endif
   }
 
   /// Row that owns edge e: largest v with offsets[v] <= e (binary search over offsets).

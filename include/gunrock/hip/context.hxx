@@ -23,6 +23,7 @@
 #include <gunrock/hip/runtime.hxx>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include <thrust/execution_policy.h>
 #include <thrust/system/hip/execution_policy.h>
@@ -149,6 +150,9 @@ struct operator_options_t {
   unsigned hub_threshold = 1024;
   /// Edges per chunk of such a list (one persistent workgroup step).
   unsigned chunk_edges = 1024;
+  /// Persistent workgroups per CU for the tile / chunk kernels.
+  unsigned tile_blocks_per_cu = 8;
+  unsigned chunk_blocks_per_cu = 4;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -243,6 +247,11 @@ class standard_context_t {
 
  private:
   void init() {
+    // tuning knobs for experiments (defaults are the measured best)
+    if (const char* e = std::getenv("GRX_TILE_BLOCKS_PER_CU"))
+      options_.tile_blocks_per_cu = (unsigned)std::atoi(e);
+    if (const char* e = std::getenv("GRX_CHUNK_BLOCKS_PER_CU"))
+      options_.chunk_blocks_per_cu = (unsigned)std::atoi(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));
     GRX_HIP_CHECK(hipGetDeviceProperties(&props_, ordinal_));
     timer_ = std::make_unique<util::timer_t>(stream_);

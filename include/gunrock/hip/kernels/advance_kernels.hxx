@@ -52,7 +52,10 @@ using operators::advance_io_type_t;
 constexpr int ADV_BLOCK = 256;                    // threads per workgroup
 constexpr int ADV_WAVES = ADV_BLOCK / wave_size;  // 4
 constexpr int ADV_WQCAP = 512;                    // entries of one wavefront's output queue
-constexpr int ADV_UNROLL = 4;                     // independent edges in flight per lane
+#ifndef GRX_ADV_UNROLL
+#define GRX_ADV_UNROLL 4
+#endif
+constexpr int ADV_UNROLL = GRX_ADV_UNROLL;        // independent edges in flight per lane
 
 enum counter_slot : int {
   C_OUT = 0,        ///< output cursor (elements)

@@ -56,7 +56,11 @@ namespace detail {
 #if defined(__HIP_DEVICE_COMPILE__)
 template <typename type_t>
 __device__ __forceinline__ type_t peek(type_t* address) {
+#ifdef GRX_ATOMIC_PRETEST_PLAIN
+  return __builtin_nontemporal_load(address);  // experiment only
+#else
   return __hip_atomic_load(address, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 __device__ __forceinline__ float fmin_rmw(float* address, float value) {
   // IEEE-754 order equals signed-int order for non-negative values and reversed
@@ -106,6 +110,15 @@ template <typename type_t>
 __host__ __device__ __forceinline__ type_t min(type_t* address, type_t value) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef GRX_ATOMIC_NO_PRETEST
+#ifdef GRX_ATOMIC_MONOTONE_L1
+  // opt-in: valid only for words that never increase while a kernel runs (BFS/SSSP labels):
+  // an L1-cached copy can only be too LARGE, so "no improvement" from it is always right.
+  {
+    type_t cached = *address;
+    if (!(value < cached))
+      return cached;
+  }
+#endif
   type_t seen = detail::peek(address);
   if (!(value < seen))
     return seen;
