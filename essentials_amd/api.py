@@ -153,18 +153,14 @@ _SIGNATURES = {
                              C.c_int64, C.POINTER(C.c_int64)]),
     "grx_uniquify": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP, C.c_int64,
                                C.POINTER(C.c_int64)]),
-    "grx_comm_unique_id": (C.c_int, [_VP]),
-    "grx_comm_attach": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
-    "grx_comm_detach": (C.c_int, [_VP]),
-    "grx_graph_rmat_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
-                                           C.c_int, C.POINTER(_VP), C.POINTER(C.c_int32),
-                                           C.POINTER(C.c_int32)]),
-    "grx_graph_partition": (C.c_int, [_VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int32),
+    "grx_graph_partition": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]),
-    "grx_bfs_partitioned": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP,
-                                      C.POINTER(_Options), C.POINTER(_Stats)]),
-    "grx_sssp_partitioned": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP,
-                                       C.POINTER(_Options), C.POINTER(_Stats)]),
+    "grx_partitioned_expand": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, C.c_int32,
+                                         _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64,
+                                         C.POINTER(C.c_int64)]),
+    "grx_partitioned_admit": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, _VP, C.c_int32,
+                                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int64,
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 }
 

@@ -1,0 +1,311 @@
+/**
+ * @file partitioned.hip
+ * @brief C ABI: the device side of vertex-partitioned (multi-GPU) traversals --
+ * graph slicing, the local superstep (advance + pack) and the admission kernel.
+ * The collective between the two is issued by the host (torch.distributed /
+ * RCCL all-gather), see essentials_amd/distributed.py and include/essentials_amd.h.
+ *
+ * No reference counterpart: the reference's operators throw for more than one
+ * context (advance.hxx:125-128); design per SURVEY.md 8(e).
+ */
+#include "capi_internal.hxx"
+
+#include <algorithm>
+#include <vector>
+
+using namespace essentials_amd;
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+    slice_offsets_kernel(const int32_t* full, int32_t n, int32_t lo, int32_t hi, int32_t* local) {
+  const int32_t base = full[lo];
+  const int32_t top = full[hi];
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i <= n; i += (int64_t)gridDim.x * 256) {
+    int32_t o = full[i];
+    o = o < base ? base : (o > top ? top : o);
+    local[i] = o - base;  // rows outside [lo,hi) become empty
+  }
+}
+
+/// Pack the finds of one superstep, ONE pair per vertex (a vertex improved several times
+/// appears several times in the raw output): send[1 + k] = (vertex | label bits << 32), the
+/// label read after the advance, i.e. the best this rank knows.  counters[C_SELECT] counts them.
+template <typename label_t>
+__global__ void __launch_bounds__(256)
+    pack_pairs_kernel(const int32_t* found, int64_t count, const label_t* labels, int32_t* sent,
+                      int32_t round, int64_t* send, int64_t send_capacity,
+                      unsigned long long* counters) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t rounds = (count + stride - 1) / stride;
+  const int lane = hip::lane_id();
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t i = r * stride + blockIdx.x * 256ll + threadIdx.x;
+    bool first = false;
+    int32_t v = -1;
+    if (i < count) {
+      v = found[i];
+      first = atomicExch(&sent[v], round) != round;  // exactly one packer per vertex and round
+    }
+    const unsigned long long m = __ballot(first);
+    if (m) {
+      unsigned long long base = 0;
+      if (lane == 0)
+        base = atomicAdd(&counters[hip::kernels::C_SELECT], (unsigned long long)__popcll(m));
+      base = __shfl(base, 0, hip::wave_size);
+      if (first) {
+        const long long at = (long long)(base + hip::rank_in_mask(m));
+        if (at < send_capacity - 1) {
+          const label_t l = labels[v];
+          uint32_t bits;
+          __builtin_memcpy(&bits, &l, 4);
+          send[1 + at] = (int64_t)(((uint64_t)bits << 32) | (uint32_t)v);
+        } else {
+          counters[hip::kernels::C_OVERFLOW] = 1ull;
+        }
+      }
+    }
+  }
+}
+
+__global__ void publish_count_kernel(int64_t* send, const unsigned long long* counters) {
+  send[0] = (int64_t)counters[hip::kernels::C_SELECT];
+}
+
+template <typename label_t>
+__global__ void __launch_bounds__(256)
+    admit_kernel(label_t* labels, int32_t* stamp, int32_t round, const int64_t* recv, int32_t world,
+                 int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* next,
+                 unsigned long long next_capacity, unsigned long long* counters) {
+  // grid-stride over (rank, entry); ranks' slots are padded to `slot` words.  The trip count
+  // is wave-uniform so that admitted vertices can be ranked with one ballot per wavefront.
+  const int64_t per_rank = slot - 1;
+  const int64_t total = (int64_t)world * per_rank;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t rounds = (total + stride - 1) / stride;
+  const int lane = hip::lane_id();
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t t = r * stride + blockIdx.x * 256ll + threadIdx.x;
+    bool admit = false;
+    int32_t v = -1;
+    if (t < total) {
+      const int32_t p = (int32_t)(t / per_rank);
+      const int64_t i = t - (int64_t)p * per_rank;
+      const int64_t* seg = recv + (int64_t)p * slot;
+      const int64_t cnt = seg[0] < per_rank ? seg[0] : per_rank;
+      if (i < cnt) {
+        const uint64_t word = (uint64_t)seg[1 + i];
+        v = (int32_t)(uint32_t)word;
+        const uint32_t bits = (uint32_t)(word >> 32);
+        label_t l;
+        __builtin_memcpy(&l, &bits, 4);
+        // this rank's own advance already improved its own finds
+        const bool fresh = (p == me) ? true : (l < math::atomic::min(&labels[v], l));
+        if (fresh && v >= lo && v < hi && stamp[v] != round) {
+          stamp[v] = round;  // one copy per superstep (benign race, cf. sssp.hxx:126-136)
+          admit = true;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(admit);
+    if (m) {
+      unsigned long long base = 0;
+      if (lane == 0)
+        base = atomicAdd(&counters[hip::kernels::C_OUT], (unsigned long long)__popcll(m));
+      base = __shfl(base, 0, hip::wave_size);
+      if (admit) {
+        const unsigned long long at = base + hip::rank_in_mask(m);
+        if (at < next_capacity)
+          next[at] = v;
+        else
+          counters[hip::kernels::C_OVERFLOW] = 1ull;
+      }
+    }
+  }
+}
+
+template <typename label_t>
+int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_t edge_op,
+              label_t* labels, int32_t iparam, const int32_t* d_frontier, int64_t n_frontier,
+              int32_t* d_scratch, int64_t scratch_capacity, int32_t* d_sent, int64_t* d_send,
+              int64_t send_capacity, int64_t* n_found) {
+  return with_load_balance(o.load_balance, [&](auto lb_tag) -> int {
+    constexpr auto lb = decltype(lb_tag)::value;
+    using operators::advance_direction_t;
+    using operators::advance_io_type_t;
+    auto& sc = ctx->single();
+    scoped_options scope(sc, &o);
+    sc.options().holes_layout = false;  // the exchange needs packed discoveries
+    graph_type G = local->view();
+    auto fin = frontier_type::wrap(const_cast<int32_t*>(d_frontier), (std::size_t)n_frontier,
+                                   (std::size_t)(n_frontier ? n_frontier : 1));
+    auto fout = frontier_type::wrap(d_scratch, 0, (std::size_t)scratch_capacity);
+    hip::device_array_t<edge_t> segments;
+    if (edge_op == GRX_OP_BFS) {
+      int* depth = reinterpret_cast<int*>(labels);
+      const int next_level = iparam + 1;
+      auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                           edge_t const& e, weight_t const& w) -> bool {
+        return next_level < math::atomic::min(&depth[dst], next_level);
+      };
+      operators::advance::execute<lb, advance_direction_t::forward, advance_io_type_t::vertices,
+                                  advance_io_type_t::vertices>(G, visit, &fin, &fout, segments,
+                                                               *ctx->mc);
+    } else {
+      float* dist = reinterpret_cast<float*>(labels);
+      auto relax = [dist] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                              edge_t const& e, weight_t const& w) -> bool {
+        float through = thread::load(&dist[src]) + w;
+        return through < math::atomic::min(&dist[dst], through);
+      };
+      operators::advance::execute<lb, advance_direction_t::forward, advance_io_type_t::vertices,
+                                  advance_io_type_t::vertices>(G, relax, &fin, &fout, segments,
+                                                               *ctx->mc);
+    }
+    const int64_t count = (int64_t)fout.get_number_of_elements();
+    auto& ws = sc.workspace();
+    unsigned long long* counters = ws.counters();
+    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
+                                 sc.stream()));
+    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_OVERFLOW, 0, sizeof(unsigned long long),
+                                 sc.stream()));
+    if (count) {
+      const unsigned grid = (unsigned)std::min<int64_t>((count + 255) / 256,
+                                                        (int64_t)sc.compute_units() * 8);
+      pack_pairs_kernel<label_t><<<grid, 256, 0, sc.stream()>>>(d_scratch, count, labels, d_sent,
+                                                                iparam, d_send, send_capacity,
+                                                                counters);
+    }
+    publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
+    GRX_HIP_CHECK(hipGetLastError());
+    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), counters, 24 * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, sc.stream()));
+    sc.synchronize();
+    error::throw_if_exception(ws.mirror()[hip::kernels::C_OVERFLOW] != 0,
+                              "grx_partitioned_expand: send buffer too small (needs V + 1 words)");
+    *n_found = (int64_t)ws.mirror()[hip::kernels::C_SELECT];
+    return (int)GRX_OK;
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_graph_partition(grx_graph_t full, int rank, int world, grx_graph_t* out,
+                        int32_t* row_begin, int32_t* row_end) {
+  if (!full || !out || world < 1 || rank < 0 || rank >= world)
+    return invalid("grx_graph_partition: bad arguments");
+  return guarded([&] {
+    const int32_t n = full->n_rows;
+    std::vector<int32_t> ap((std::size_t)n + 1);
+    GRX_HIP_CHECK(hipMemcpy(ap.data(), full->d_ap, ap.size() * 4, hipMemcpyDeviceToHost));
+    // edge-balanced split points: first row whose offset reaches k * E / world
+    auto split = [&](int k) -> int32_t {
+      if (k <= 0) return 0;
+      if (k >= world) return n;
+      const int64_t target = (int64_t)ap[n] * k / world;
+      return (int32_t)(std::lower_bound(ap.begin(), ap.end(), (int32_t)target) - ap.begin());
+    };
+    int32_t lo = split(rank), hi = split(rank + 1);
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+    if (hi < lo) hi = lo;
+    auto g = std::make_unique<grx_graph_s>();
+    g->n_rows = n;
+    g->n_cols = full->n_cols;
+    g->nnz = (int64_t)ap[hi] - ap[lo];
+    g->ap.resize((std::size_t)n + 1);
+    g->aj.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+    g->ax.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+    slice_offsets_kernel<<<1024, 256>>>(full->d_ap, n, lo, hi, g->ap.data());
+    GRX_HIP_CHECK(hipGetLastError());
+    if (g->nnz) {
+      GRX_HIP_CHECK(hipMemcpy(g->aj.data(), full->d_aj + ap[lo], (std::size_t)g->nnz * 4,
+                              hipMemcpyDeviceToDevice));
+      GRX_HIP_CHECK(hipMemcpy(g->ax.data(), full->d_ax + ap[lo], (std::size_t)g->nnz * 4,
+                              hipMemcpyDeviceToDevice));
+    }
+    GRX_HIP_CHECK(hipDeviceSynchronize());
+    g->adopt();
+    if (row_begin) *row_begin = lo;
+    if (row_end) *row_end = hi;
+    *out = g.release();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_partitioned_expand(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
+                           int32_t edge_op, void* d_labels, int32_t iparam,
+                           const int32_t* d_frontier, int64_t n_frontier, int32_t* d_scratch,
+                           int64_t scratch_capacity, int32_t* d_sent_stamp, int64_t* d_send,
+                           int64_t send_capacity, int64_t* n_found) {
+  if (!ctx || !local || !d_labels || !d_scratch || !d_send || !d_sent_stamp || !n_found ||
+      send_capacity < 2 ||
+      scratch_capacity < 1 || n_frontier < 0 || (n_frontier && !d_frontier))
+    return invalid("grx_partitioned_expand: bad arguments");
+  if (edge_op != GRX_OP_BFS && edge_op != GRX_OP_SSSP)
+    return unsupported("grx_partitioned_expand: edge_op must be GRX_OP_BFS or GRX_OP_SSSP");
+  grx_options o;
+  grx_default_options(&o);
+  if (opt)
+    o = *opt;
+  return guarded([&] {
+    if (edge_op == GRX_OP_BFS)
+      return expand_as<int32_t>(ctx, local, o, edge_op, (int32_t*)d_labels, iparam, d_frontier,
+                                n_frontier, d_scratch, scratch_capacity, d_sent_stamp, d_send,
+                                send_capacity, n_found);
+    return expand_as<float>(ctx, local, o, edge_op, (float*)d_labels, iparam, d_frontier,
+                            n_frontier, d_scratch, scratch_capacity, d_sent_stamp, d_send,
+                            send_capacity, n_found);
+  });
+}
+
+int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int32_t* d_stamp,
+                          int32_t round, const int64_t* d_recv, int32_t world, int64_t slot,
+                          int32_t me, int32_t lo, int32_t hi, int32_t* d_next, int64_t next_capacity,
+                          int64_t* n_next, int64_t* n_total_found) {
+  if (!ctx || !d_labels || !d_stamp || !d_recv || !d_next || !n_next || world < 1 || slot < 2 ||
+      me < 0 || me >= world)
+    return invalid("grx_partitioned_admit: bad arguments");
+  if (edge_op != GRX_OP_BFS && edge_op != GRX_OP_SSSP)
+    return unsupported("grx_partitioned_admit: edge_op must be GRX_OP_BFS or GRX_OP_SSSP");
+  return guarded([&] {
+    auto& sc = ctx->single();
+    auto& ws = sc.workspace();
+    unsigned long long* counters = ws.counters();
+    GRX_HIP_CHECK(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned long long), sc.stream()));
+    const int64_t total = (int64_t)world * (slot - 1);
+    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
+                                                      (int64_t)sc.compute_units() * 8);
+    if (edge_op == GRX_OP_BFS)
+      admit_kernel<int32_t><<<grid, 256, 0, sc.stream()>>>(
+          (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
+          (unsigned long long)next_capacity, counters);
+    else
+      admit_kernel<float><<<grid, 256, 0, sc.stream()>>>(
+          (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
+          (unsigned long long)next_capacity, counters);
+    GRX_HIP_CHECK(hipGetLastError());
+    // the per-rank counts sit at recv[p * slot]: fetch them with the counters
+    std::vector<int64_t> heads((std::size_t)world);
+    GRX_HIP_CHECK(hipMemcpy2DAsync(heads.data(), sizeof(int64_t), d_recv, (std::size_t)slot * 8,
+                                   sizeof(int64_t), (std::size_t)world, hipMemcpyDeviceToHost,
+                                   sc.stream()));
+    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), counters, 8 * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, sc.stream()));
+    sc.synchronize();
+    error::throw_if_exception(ws.mirror()[hip::kernels::C_OVERFLOW] != 0,
+                              "grx_partitioned_admit: next frontier capacity exceeded");
+    *n_next = (int64_t)ws.mirror()[hip::kernels::C_OUT];
+    if (n_total_found) {
+      int64_t t = 0;
+      for (auto h : heads)
+        t += h;
+      *n_total_found = t;
+    }
+    return (int)GRX_OK;
+  });
+}
+
+}  // extern "C"

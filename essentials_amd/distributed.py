@@ -1,18 +1,33 @@
 """Runners used by bench.py and the multi-process tests: one graph resident in HBM, repeated
 BFS / SSSP traversals through the C ABI.
 
-SingleRunner      one GPU, the whole graph.
-PartitionedRunner one process per GPU (torch.distributed / RCCL): 1-D vertex partition, local
-                  advance, all-gather of the per-rank output frontiers between supersteps
-                  (SURVEY.md 8e).  Defined in this module once the RCCL path is built.
+SingleRunner          one GPU, the whole graph (grx_bfs / grx_sssp).
+PartitionedTraversal  the multi-GPU superstep protocol: one process per GPU,
+                      1-D edge-balanced vertex partition, replicated labels, local advance,
+                      ALL-GATHER of the per-rank output frontiers between supersteps
+                      (torch.distributed: backend "nccl" is RCCL over xGMI), min-combine +
+                      owner admission.  The local kernels come from a `kernels` object:
+                      HipKernels (the C ABI, production) -- tests may pass another object with
+                      the same two methods to exercise the protocol on CPU ranks over gloo.
+PartitionedRunner     bench-side wrapper: R-MAT graph, slicing, repeated traversals.
+
+Exchange format (one int64 slot per rank): word 0 = number of (vertex,label) pairs the rank
+found this superstep, words 1.. = pairs (low 32 bits vertex id, high 32 bits label bits).
+A first all-gather moves a SMALL fixed slot (header + the first pairs); only when some rank found
+more than fits is a second all-gather issued with a slot sized by the largest count, which every
+rank knows from the first -- so most supersteps cost one collective and no count exchange.
 """
 from __future__ import annotations
+
+import ctypes as C
+import time
 
 import numpy as np
 
 from . import api as ea
 
 HBM_PEAK_GBPS = 8000.0
+OP_BFS, OP_SSSP = int(ea.EdgeOp.bfs), int(ea.EdgeOp.sssp)
 
 
 def bfs_algorithmic_bytes(edges_traversed: int, vertices_reached: int) -> int:
@@ -21,6 +36,22 @@ def bfs_algorithmic_bytes(edges_traversed: int, vertices_reached: int) -> int:
     return 8 * edges_traversed + 20 * vertices_reached
 
 
+def partition_bounds(row_offsets, world: int):
+    """Edge-balanced 1-D split points (the rule grx_graph_partition applies): rank k owns rows
+    [b[k], b[k+1]) where b[k] is the first row whose offset reaches k*E/world."""
+    ap = np.asarray(row_offsets)
+    n = len(ap) - 1
+    e = int(ap[n])
+    b = [0]
+    for k in range(1, world):
+        b.append(int(np.searchsorted(ap, np.int64(e) * k // world, side="left")))
+    b.append(n)
+    for k in range(1, len(b)):
+        b[k] = min(max(b[k], b[k - 1]), n)
+    return b
+
+
+# --------------------------------------------------------------------------- single GPU
 class SingleRunner:
     def __init__(self, ctx: ea.Context, scale: int, edge_factor: int, seed: int, weight_seed: int):
         import torch
@@ -77,3 +108,180 @@ class SingleRunner:
                     "mteps_enact": st.edges_traversed / max(st.elapsed_ms, 1e-9) / 1e3,
                     "frontier_slots": st.frontier_slots[:16]}
         return d
+
+
+# --------------------------------------------------------------------------- multi GPU
+class HipKernels:
+    """The production local kernels: grx_partitioned_expand / grx_partitioned_admit."""
+
+    def __init__(self, ctx: ea.Context, local_graph: ea.Graph, options: ea.Options | None = None):
+        self.ctx, self.g = ctx, local_graph
+        self.opts = (options or ea.Options())._c()
+        self.lib = ea.load_library()
+
+    def expand(self, op, labels, rnd, frontier, n_frontier, scratch, sent, send) -> int:
+        n = C.c_int64()
+        ea._check(self.lib.grx_partitioned_expand(
+            self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), rnd,
+            frontier.data_ptr() if n_frontier else None, n_frontier, scratch.data_ptr(),
+            scratch.numel(), sent.data_ptr(), send.data_ptr(), send.numel(), C.byref(n)),
+            "grx_partitioned_expand")
+        return n.value
+
+    def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
+        n_next, total = C.c_int64(), C.c_int64()
+        ea._check(self.lib.grx_partitioned_admit(
+            self.ctx._h, op, labels.data_ptr(), stamp.data_ptr(), rnd, recv.data_ptr(), world, slot,
+            rank, lo, hi, nxt.data_ptr(), nxt.numel(), C.byref(n_next), C.byref(total)),
+            "grx_partitioned_admit")
+        return n_next.value, total.value
+
+
+class PartitionedTraversal:
+    """BSP supersteps of a vertex-partitioned BFS / SSSP over `dist` (torch.distributed or None)."""
+
+    SMALL_SLOT = 1 << 15  # int64 words per rank in the first all-gather (256 KiB)
+
+    def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int,
+                 local_nnz: int, device, small_slot: int | None = None):
+        import torch
+        self.torch = torch
+        self.k, self.dist = kernels, dist
+        self.rank, self.world, self.n, self.lo, self.hi = rank, world, n_global, lo, hi
+        self.device = device
+        # every rank derives the same slot sizes from (small_slot, V)
+        self.slot0 = max(2, min(int(small_slot or self.SMALL_SLOT), n_global + 2))
+        i32, i64 = torch.int32, torch.int64
+        self.stamp = torch.full((n_global,), -1, dtype=i32, device=device)
+        self.sent = torch.full((n_global,), -1, dtype=i32, device=device)
+        own = max(hi - lo, 1)
+        self.frontier = [torch.empty(own + 64, dtype=i32, device=device) for _ in range(2)]
+        self.scratch = torch.empty(max(local_nnz, 1) + n_global + 64, dtype=i32, device=device)
+        self.send = torch.zeros(n_global + 2, dtype=i64, device=device)
+        self.recv = torch.zeros(world * self.slot0, dtype=i64, device=device)
+        self._recv_big = None
+        self._backend = dist.get_backend() if dist is not None and world > 1 else None
+
+    # -- the collective -------------------------------------------------------------------
+    def _all_gather(self, recv, send):
+        """recv[world*slot] <- concatenation of every rank's send[slot]."""
+        if self.world == 1:
+            recv[: send.numel()].copy_(send)
+            return
+        if self._backend == "nccl" or not send.is_cuda:
+            self.dist.all_gather_into_tensor(recv, send)
+        else:  # gloo with device tensors (test rigs): stage through the host
+            h = send.cpu()
+            parts = [self.torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(parts, h)
+            recv.copy_(self.torch.cat(parts).to(recv.device))
+
+    def run(self, op: int, source: int, labels) -> dict:
+        """labels: replica [V] (int32 for BFS, float32 for SSSP), overwritten."""
+        torch = self.torch
+        unreached = ea.INT_UNREACHED if op == OP_BFS else ea.FLT_UNREACHED
+        labels.fill_(unreached)
+        labels[source] = 0
+        self.stamp.fill_(-1)
+        self.sent.fill_(-1)
+        cur, nxt = self.frontier
+        n_cur = 0
+        if self.lo <= source < self.hi:
+            cur[0] = source
+            n_cur = 1
+        if labels.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rounds = found_total = collectives = 0
+        while True:
+            self.k.expand(op, labels, rounds, cur, n_cur, self.scratch, self.sent, self.send)
+            slot = self.slot0
+            recv = self.recv
+            self._all_gather(recv, self.send[:slot])
+            collectives += 1
+            heads = recv.view(self.world, slot)[:, 0]
+            counts = heads.cpu() if heads.is_cuda else heads
+            most = int(counts.max())
+            if most == 0:
+                break  # no rank improved anything: every replica is final
+            if most > slot - 1:
+                slot = min(((most + 1 + 4095) // 4096) * 4096, self.send.numel())
+                if self._recv_big is None or self._recv_big.numel() < self.world * slot:
+                    self._recv_big = torch.zeros(self.world * slot, dtype=torch.int64,
+                                                 device=self.device)
+                recv = self._recv_big[: self.world * slot]
+                self._all_gather(recv, self.send[:slot])
+                collectives += 1
+            n_cur, total = self.k.admit(op, labels, self.stamp, rounds, recv, self.world, slot,
+                                        self.rank, self.lo, self.hi, nxt)
+            found_total += total
+            cur, nxt = nxt, cur
+            rounds += 1
+        if labels.is_cuda:
+            torch.cuda.synchronize()
+        return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
+                "pairs_exchanged": found_total, "collectives": collectives}
+
+
+class PartitionedRunner:
+    """bench.py's N > 1 runner: every rank builds the R-MAT graph, keeps its slice."""
+
+    def __init__(self, ctx: ea.Context, dist, scale, edge_factor, seed, weight_seed,
+                 options: ea.Options | None = None):
+        import torch
+        self.ctx, self.dist = ctx, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        full = ea.Graph.rmat(ctx, scale, edge_factor, seed, weight_seed, True)
+        self.n, self.nnz = full.n_rows, full.nnz
+        self._host = full.to_host() if self.rank == 0 else None
+        ap = full.to_host()[0] if self._host is None else self._host[0]
+        self._deg = np.diff(ap).astype(np.int64)
+        h = ea._VP()
+        lo, hi = C.c_int32(), C.c_int32()
+        ea._check(ea.load_library().grx_graph_partition(full._h, self.rank, self.world, C.byref(h),
+                                                        C.byref(lo), C.byref(hi)),
+                  "grx_graph_partition")
+        self.local = ea.Graph(h)
+        self.lo, self.hi = lo.value, hi.value
+        assert [self.lo, self.hi] == partition_bounds(ap, self.world)[self.rank:self.rank + 2]
+        full.close()
+        dev = f"cuda:{ctx.device}"
+        self.depth = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.distance = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist, self.rank,
+                                         self.world, self.n, self.lo, self.hi, self.local.nnz, dev)
+        self._deg_dev = torch.from_numpy(self._deg).to(dev)
+        self.last = {}
+
+    def host_csr(self):
+        return self._host
+
+    def global_degrees(self):
+        return self._deg
+
+    def _edges(self, labels, unreached):
+        return int(self._deg_dev[labels != unreached].sum().item())
+
+    def bfs(self, source: int, opts=None) -> int:
+        self.last["bfs"] = self.trav.run(OP_BFS, source, self.depth)
+        return self._edges(self.depth, ea.INT_UNREACHED)
+
+    def sssp(self, source: int, opts=None) -> int:
+        self.last["sssp"] = self.trav.run(OP_SSSP, source, self.distance)
+        return self._edges(self.distance, ea.FLT_UNREACHED)
+
+    def bfs_roofline(self, source: int, lb) -> dict:
+        st = self.trav.run(OP_BFS, source, self.depth)
+        edges = self._edges(self.depth, ea.INT_UNREACHED)
+        reached = int((self.depth != ea.INT_UNREACHED).sum().item())
+        nbytes = bfs_algorithmic_bytes(edges, reached)
+        achieved = nbytes / (st["elapsed_ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * self.world,
+                "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * self.world), "traffic": None,
+                "kernel": "whole partitioned BFS (supersteps incl. all-gather), aggregate over ranks",
+                "algorithmic_bytes": nbytes, "elapsed_ms": st["elapsed_ms"],
+                "supersteps": st["supersteps"]}
+
+    def detail(self) -> dict:
+        return {k: dict(v, rows_owned=self.hi - self.lo, local_edges=self.local.nnz)
+                for k, v in self.last.items()}

@@ -91,7 +91,7 @@ typedef struct grx_graph_s* grx_graph_t;     /* graph::graph_t over CSR, graph/b
 typedef struct grx_options {
   int32_t load_balance;     /* grx_load_balance; default GRX_LB_BLOCK_MAPPED (what bfs.hxx spells) */
   int32_t holes_layout;     /* 1: one output slot per traversed edge, -1 holes (reference layout) */
-  int32_t hub_threshold;    /* 0: default (1024): longer lists are cut into chunks               */
+  int32_t hub_threshold;    /* 0: default (256): longer lists are cut into chunks                */
   int32_t max_iterations;   /* 0: run to convergence                                              */
   float frontier_sizing_factor; /* 0: default 1.5 (enactor.hxx:36)                                */
   int32_t collect_kernel_time;  /* 1: event-time the advance kernels (adds two events per launch)  */
@@ -184,30 +184,45 @@ int grx_filter(grx_context_t ctx, grx_graph_t g, int32_t algorithm, int32_t vert
 int grx_uniquify(grx_context_t ctx, int32_t algorithm, int32_t best_effort, int32_t* d_input,
                  int64_t n_input, int32_t* d_output, int64_t output_capacity, int64_t* n_output);
 
-/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
+/* ---- multi-GPU: one process per GPU, frontier all-gather over RCCL/xGMI ------------------ */
 /* The reference declares multi_context_t for several devices but every operator throws for
- * size() != 1 (advance.hxx:125-128); this is new functionality. */
-#define GRX_UNIQUE_ID_BYTES 128
-int grx_comm_unique_id(void* h_id /* GRX_UNIQUE_ID_BYTES, rank 0 only; broadcast by the host */);
-int grx_comm_attach(grx_context_t ctx, const void* h_id, int rank, int world_size);
-int grx_comm_detach(grx_context_t ctx);
-/* Rows [row_begin,row_end) of the R-MAT graph as a rank-local CSR with GLOBAL column ids;
- * split points balance edges (prefix of the global row offsets). */
-int grx_graph_rmat_partition(grx_context_t ctx, uint32_t scale, uint32_t edge_factor,
-                             uint64_t seed, uint64_t weight_seed, int symmetrize,
-                             grx_graph_t* out, int32_t* row_begin, int32_t* row_end);
-/* Rank-local slice of an existing (replicated) graph: same contract as above. */
-int grx_graph_partition(grx_context_t ctx, grx_graph_t full, grx_graph_t* out,
+ * size() != 1 (advance.hxx:125-128); this is new functionality.
+ *
+ * Model: 1-D vertex partition.  Rank r owns rows [row_begin,row_end); its local CSR keeps GLOBAL
+ * vertex ids and has all V rows, the rows it does not own being empty.  Every rank holds a
+ * replica of the label array (BFS depth / SSSP distance).  One BSP superstep =
+ *   grx_partitioned_expand   local advance over the owned input frontier (any schedule) with the
+ *                            BFS / SSSP functor on the replica; the vertices it improved are
+ *                            packed as [count | (vertex,label) ...] into the rank's send slot
+ *   all-gather of the send slots over RCCL (done by the host: torch.distributed / ncclAllGather)
+ *   grx_partitioned_admit    min-combine every other rank's pairs into the replica and append
+ *                            the owned, improved vertices to the next input frontier
+ * The host loop and the collective live in essentials_amd/distributed.py. */
+
+/* Rank-local slice of a replicated graph; split points balance EDGES (prefix of row offsets). */
+int grx_graph_partition(grx_graph_t full, int rank, int world_size, grx_graph_t* out,
                         int32_t* row_begin, int32_t* row_end);
-/* Vertex-partitioned BFS / SSSP: local advance over owned frontier vertices, RCCL
- * all-gather of the per-rank output frontiers between BSP supersteps, min-combine into
- * every rank's replica of the label array.  d_distances: [n_rows of the FULL graph]. */
-int grx_bfs_partitioned(grx_context_t ctx, grx_graph_t local, int32_t n_global,
-                        int32_t row_begin, int32_t row_end, int32_t source, int32_t* d_distances,
-                        const grx_options* opt, grx_stats* stats);
-int grx_sssp_partitioned(grx_context_t ctx, grx_graph_t local, int32_t n_global,
-                         int32_t row_begin, int32_t row_end, int32_t source, float* d_distances,
-                         const grx_options* opt, grx_stats* stats);
+/* d_labels: replica [V] (int32 depth for GRX_OP_BFS, float distance for GRX_OP_SSSP).
+ * round: superstep number (the BFS level).  d_frontier / n_frontier: owned input frontier
+ * (global ids).  d_scratch: int32[scratch_capacity] workspace for the raw output frontier
+ * (>= sum of degrees of the frontier; local nnz + V is enough for a duplicate-free frontier).
+ * d_sent_stamp: int32[V], -1 initially: a vertex improved several times in one superstep is
+ * packed once.  d_send: int64[send_capacity >= V + 1]; word 0 receives the number of pairs,
+ * words 1.. the pairs (low 32 bits vertex, high 32 bits label bits).  *n_found = that count. */
+int grx_partitioned_expand(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
+                           int32_t edge_op, void* d_labels, int32_t round,
+                           const int32_t* d_frontier, int64_t n_frontier, int32_t* d_scratch,
+                           int64_t scratch_capacity, int32_t* d_sent_stamp, int64_t* d_send,
+                           int64_t send_capacity, int64_t* n_found);
+/* d_recv: int64[world_size * slot] gathered send slots.  Pairs of other ranks are min-combined
+ * into d_labels; a vertex is appended to d_next (capacity next_capacity) when it is owned
+ * (row_begin <= v < row_end), its label improved (or it is one of this rank's own discoveries)
+ * and d_stamp[v] != round (then d_stamp[v] = round: one copy per superstep, like the bypass
+ * filter of reference algorithms/sssp.hxx:126-136).  *n_total_found = sum of all ranks' counts. */
+int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int32_t* d_stamp,
+                          int32_t round, const int64_t* d_recv, int32_t world_size, int64_t slot,
+                          int32_t my_rank, int32_t row_begin, int32_t row_end, int32_t* d_next,
+                          int64_t next_capacity, int64_t* n_next, int64_t* n_total_found);
 
 /* ---- measurement helpers ------------------------------------------------- */
 /* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:

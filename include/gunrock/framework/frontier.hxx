@@ -76,6 +76,14 @@ class frontier_t {
         num_elements_(size),
         resizing_factor_(frontier_resizing_factor) {}
 
+  /// Frontier over caller-owned device memory holding `size` elements (cannot grow).
+  static frontier_t wrap(type_t* external, std::size_t size, std::size_t capacity) {
+    frontier_t f;
+    f.storage_ = std::make_shared<hip::buffer_t<type_t>>(external, capacity);
+    f.num_elements_ = size;
+    return f;
+  }
+
   static constexpr frontier_kind_t get_kind() { return _kind; }
   static constexpr frontier_view_t get_view() { return _view; }
 

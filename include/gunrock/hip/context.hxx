@@ -147,7 +147,7 @@ struct operator_options_t {
   /// false (default): only accepted neighbours are written, packed.
   bool holes_layout = false;
   /// Neighbour lists at least this long are cut into chunks spread over the GPU.
-  unsigned hub_threshold = 1024;
+  unsigned hub_threshold = 256;
   /// Edges per chunk of such a list (one persistent workgroup step).
   unsigned chunk_edges = 1024;
   /// Persistent workgroups per CU for the tile / chunk kernels.

@@ -98,13 +98,17 @@ class buffer_t {
  public:
   buffer_t() = default;
   explicit buffer_t(std::size_t n) { reserve(n); }
+  /// Non-owning view of caller memory: never freed, cannot grow.
+  buffer_t(type_t* external, std::size_t capacity) : ptr_(external), cap_(capacity), owns_(false) {}
   buffer_t(const buffer_t&) = delete;
   buffer_t& operator=(const buffer_t&) = delete;
-  buffer_t(buffer_t&& o) noexcept : ptr_(o.ptr_), cap_(o.cap_) { o.ptr_ = nullptr; o.cap_ = 0; }
+  buffer_t(buffer_t&& o) noexcept : ptr_(o.ptr_), cap_(o.cap_), owns_(o.owns_) {
+    o.ptr_ = nullptr; o.cap_ = 0;
+  }
   buffer_t& operator=(buffer_t&& o) noexcept {
     if (this != &o) {
       release();
-      ptr_ = o.ptr_; cap_ = o.cap_;
+      ptr_ = o.ptr_; cap_ = o.cap_; owns_ = o.owns_;
       o.ptr_ = nullptr; o.cap_ = 0;
     }
     return *this;
@@ -118,6 +122,7 @@ class buffer_t {
   void reserve(std::size_t n, std::size_t keep = 0, hipStream_t stream = nullptr) {
     if (n <= cap_)
       return;
+    error::throw_if_exception(!owns_, "caller-provided frontier storage is too small");
     type_t* fresh = memory::allocate<type_t>(n * sizeof(type_t));
     if (ptr_ && keep) {
       GRX_HIP_CHECK(hipMemcpyAsync(fresh, ptr_, keep * sizeof(type_t), hipMemcpyDeviceToDevice, stream));
@@ -129,15 +134,17 @@ class buffer_t {
   }
 
   void release() {
-    if (ptr_)
+    if (ptr_ && owns_)
       (void)hipFree(ptr_);
     ptr_ = nullptr;
     cap_ = 0;
+    owns_ = true;
   }
 
  private:
   type_t* ptr_ = nullptr;
   std::size_t cap_ = 0;
+  bool owns_ = true;
 };
 
 /**

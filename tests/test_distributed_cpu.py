@@ -1,0 +1,136 @@
+"""The multi-GPU superstep protocol on CPU ranks: world_size 2 (and 3) over gloo.
+
+essentials_amd.distributed.PartitionedTraversal is the production host loop (exchange format,
+small-slot / big-slot all-gather, termination, frontier double buffering).  Here its `kernels`
+object is a numpy restatement of grx_partitioned_expand / grx_partitioned_admit (TEST ONLY --
+the product's kernels are HIP and have no CPU form), so that the protocol itself runs in real
+separate processes over a real process group.  The result on every rank must equal the oracle's
+single-process answer.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from essentials_amd.distributed import (OP_BFS, OP_SSSP, PartitionedTraversal,  # noqa: E402
+                                        partition_bounds)
+
+
+class NumpyKernels:
+    """CPU stand-in for HipKernels with the SAME contracts (include/essentials_amd.h)."""
+
+    def __init__(self, Ap, Aj, Ax, lo, hi):
+        # local CSR: all V rows, rows outside [lo,hi) empty (what grx_graph_partition builds)
+        base, top = Ap[lo], Ap[hi]
+        self.ap = (np.clip(Ap, base, top) - base).astype(np.int64)
+        self.aj = Aj[base:top]
+        self.ax = Ax[base:top]
+
+    def expand(self, op, labels, iparam, frontier, n_frontier, scratch, sent, send):
+        lab = labels.numpy()
+        snt = sent.numpy()
+        found = []
+        for v in frontier.numpy()[:n_frontier]:
+            for e in range(self.ap[v], self.ap[v + 1]):
+                d = self.aj[e]
+                new = (iparam + 1) if op == OP_BFS else np.float32(lab[v] + self.ax[e])
+                if new < lab[d]:
+                    lab[d] = new
+                    if snt[d] != iparam:        # packed once per vertex and superstep
+                        snt[d] = iparam
+                        found.append(d)
+        s = send.numpy()
+        s[0] = len(found)
+        k = min(len(found), len(s) - 1)
+        if k:
+            f = np.array(found[:k], np.int64)
+            bits = lab[f].view(np.uint32).astype(np.int64)
+            s[1:1 + k] = (bits << 32) | f
+        return len(found)
+
+    def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
+        lab, st, r, out = labels.numpy(), stamp.numpy(), recv.numpy().reshape(world, slot), nxt.numpy()
+        n, total = 0, 0
+        for p in range(world):
+            cnt = int(r[p, 0]); total += cnt
+            for w in r[p, 1:1 + cnt]:
+                v = int(w & 0xFFFFFFFF)
+                l = np.array([(int(w) >> 32) & 0xFFFFFFFF], np.uint32).view(lab.dtype)[0]
+                fresh = True if p == rank else bool(l < lab[v])
+                if p != rank and fresh:
+                    lab[v] = l
+                if fresh and lo <= v < hi and st[v] != rnd:
+                    st[v] = rnd
+                    out[n] = v; n += 1
+        return n, total
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    o = Oracle()
+    n, Ap, Aj, Ax = o.rmat_csr(scale, 8, seed, wseed)
+    b = partition_bounds(Ap, world)
+    lo, hi = b[rank], b[rank + 1]
+    k = NumpyKernels(Ap, np.ascontiguousarray(Aj), np.ascontiguousarray(Ax), lo, hi)
+    trav = PartitionedTraversal(k, dist, rank, world, n, lo, hi, int(Ap[hi] - Ap[lo]), "cpu",
+                                small_slot=small_slot)
+    ok = True
+    why = []
+    for s in sources:
+        depth = torch.empty(n, dtype=torch.int32)
+        st = trav.run(OP_BFS, s, depth)
+        want, _ = o.bfs_heap(Ap, Aj, s)
+        if not (depth.numpy() == want).all():
+            ok = False; why.append(f"bfs {s}: {int((depth.numpy() != want).sum())} wrong")
+        distance = torch.empty(n, dtype=torch.float32)
+        trav.run(OP_SSSP, s, distance)
+        wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
+        if not (distance.numpy().view(np.uint32) == wantw.view(np.uint32)).all():
+            ok = False; why.append(f"sssp {s} wrong")
+        reached = int((want != 2**31 - 1).sum())
+        if st["collectives"] < st["supersteps"] or (reached > 1 and st["supersteps"] < 2):
+            ok = False; why.append(f"stats {s}: {st}")
+    open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").write(str(why))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,small_slot", [(2, None), (2, 8), (3, 64)])
+def test_partitioned_traversal_gloo(tmp_path, world, small_slot):
+    """small_slot 8 / 64 forces the second (big-slot) all-gather on the wide levels."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path)),
+             nprocs=world, join=True)
+    names = sorted(os.listdir(tmp_path))
+    notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}
+    assert names == [f"rank{r}.ok" for r in range(world)], notes
+
+
+def test_partition_bounds_balance_edges():
+    from oracle.oracle import Oracle
+    o = Oracle()
+    n, Ap, Aj, Ax = o.rmat_csr(12, 16, 1, 0)
+    for world in (1, 2, 4, 8):
+        b = partition_bounds(Ap, world)
+        assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:]))
+        per = [int(Ap[b[k + 1]] - Ap[b[k]]) for k in range(world)]
+        assert sum(per) == int(Ap[n])
+        # no rank exceeds its fair share by more than the largest single row
+        assert max(per) <= Ap[n] / world + np.diff(Ap).max()

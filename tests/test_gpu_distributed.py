@@ -1,0 +1,120 @@
+"""The vertex-partitioned path with the real HIP kernels.  A 1-GPU box cannot run RCCL between
+two ranks on one device, so the 2-rank case uses the gloo backend with both ranks sharing GPU 0
+(the collective is staged through the host; everything else -- slicing, local advance, pack,
+admit -- is the production code).  The nccl (=RCCL) branch of the same loop is what bench.py uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_partition_slices_cover_the_graph(oracle):
+    import ctypes as C
+    import essentials_amd as ea
+    from essentials_amd import api
+    from essentials_amd.distributed import partition_bounds
+    ctx = ea.Context(0)
+    g = ea.Graph.rmat(ctx, 12, 16, 1, 7)
+    Ap, Aj, Ax = g.to_host()
+    for world in (1, 2, 3, 8):
+        b = partition_bounds(Ap, world)
+        cols = []
+        for r in range(world):
+            h, lo, hi = api._VP(), C.c_int32(), C.c_int32()
+            api._check(api.load_library().grx_graph_partition(g._h, r, world, C.byref(h), C.byref(lo),
+                                                              C.byref(hi)), "partition")
+            loc = ea.Graph(h)
+            assert (lo.value, hi.value) == (b[r], b[r + 1])
+            lap, laj, lax = loc.to_host()
+            assert loc.n_rows == g.n_rows and loc.nnz == Ap[hi.value] - Ap[lo.value]
+            deg = np.diff(lap)
+            assert (deg[:lo.value] == 0).all() and (deg[hi.value:] == 0).all()
+            assert (deg[lo.value:hi.value] == np.diff(Ap)[lo.value:hi.value]).all()
+            assert (laj == Aj[Ap[lo.value]:Ap[hi.value]]).all()
+            assert (lax == Ax[Ap[lo.value]:Ap[hi.value]]).all()
+            cols.append(laj)
+        assert (np.concatenate(cols) == Aj).all()
+
+
+def test_partitioned_world1_matches_oracle(oracle):
+    import torch
+    import essentials_amd as ea
+    from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
+    ctx = ea.Context(0)
+    g = ea.Graph.rmat(ctx, 14, 16, 1, 7)
+    Ap, Aj, Ax = g.to_host()
+    for small_slot in (None, 16):
+        trav = PartitionedTraversal(HipKernels(ctx, g), None, 0, 1, g.n_rows, 0, g.n_rows, g.nnz,
+                                    "cuda:0", small_slot=small_slot)
+        for s in (0, 7217):
+            depth = torch.empty(g.n_rows, dtype=torch.int32, device="cuda")
+            st = trav.run(OP_BFS, s, depth)
+            want, _ = oracle.bfs_heap(Ap, Aj, s)
+            assert (depth.cpu().numpy() == want).all()
+            dist_ = torch.empty(g.n_rows, dtype=torch.float32, device="cuda")
+            trav.run(OP_SSSP, s, dist_)
+            wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, s)
+            assert (dist_.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all()
+
+
+def _rank(rank, world, port, scale, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import essentials_amd as ea
+    from essentials_amd import api
+    from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
+    from oracle.oracle import Oracle
+    o = Oracle()
+    torch.cuda.set_device(0)
+    ctx = ea.Context(0)
+    full = ea.Graph.rmat(ctx, scale, 16, 1, 7)
+    Ap, Aj, Ax = full.to_host()
+    h, lo, hi = api._VP(), C.c_int32(), C.c_int32()
+    api._check(api.load_library().grx_graph_partition(full._h, rank, world, C.byref(h), C.byref(lo),
+                                                      C.byref(hi)), "partition")
+    local = ea.Graph(h)
+    notes = []
+    for lb in (ea.LoadBalance.block_mapped, ea.LoadBalance.merge_path):
+        trav = PartitionedTraversal(HipKernels(ctx, local, ea.Options(load_balance=lb)), dist, rank,
+                                    world, full.n_rows, lo.value, hi.value, local.nnz, "cuda:0",
+                                    small_slot=64 if lb == ea.LoadBalance.merge_path else None)
+        for s in (0, 1830):
+            depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+            trav.run(OP_BFS, s, depth)
+            want, _ = o.bfs_heap(Ap, Aj, s)
+            if not (depth.cpu().numpy() == want).all():
+                notes.append(f"bfs {s} {lb}")
+            d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+            trav.run(OP_SSSP, s, d)
+            wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
+            if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
+                notes.append(f"sssp {s} {lb}")
+    open(os.path.join(out_dir, f"rank{rank}." + ("bad" if notes else "ok")), "w").write(str(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_two_ranks_share_one_gpu(tmp_path, world):
+    import torch.multiprocessing as mp
+    mp.spawn(_rank, args=(world, _free_port(), 12, str(tmp_path)), nprocs=world, join=True)
+    names = sorted(os.listdir(tmp_path))
+    notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}
+    assert names == [f"rank{r}.ok" for r in range(world)], notes
