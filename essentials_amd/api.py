@@ -180,6 +180,13 @@ def load_library():
         raise EngineError(
             f"{_LIB_PATH} is missing: build it with `python -m essentials_amd.build` "
             "(hipcc --offload-arch=gfx950). essentials_amd has no CPU path.")
+    # torch ships its own copy of the HIP runtime (same SONAME as /opt/rocm's): load torch's
+    # first so that this process has ONE runtime -- with the order reversed torch later fails
+    # with "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

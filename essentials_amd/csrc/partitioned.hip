@@ -101,10 +101,11 @@ __global__ void __launch_bounds__(256)
         __builtin_memcpy(&l, &bits, 4);
         // this rank's own advance already improved its own finds
         const bool fresh = (p == me) ? true : (l < math::atomic::min(&labels[v], l));
-        if (fresh && v >= lo && v < hi && stamp[v] != round) {
-          stamp[v] = round;  // one copy per superstep (benign race, cf. sssp.hxx:126-136)
+        // exactly one copy per superstep (the reference's SSSP bypass predicate,
+        // sssp.hxx:126-136, tolerates duplicates; here the frontier stays duplicate-free so
+        // that its work is bounded by the rank's edge count)
+        if (fresh && v >= lo && v < hi && atomicExch(&stamp[v], round) != round)
           admit = true;
-        }
       }
     }
     const unsigned long long m = __ballot(admit);

@@ -122,7 +122,9 @@ class buffer_t {
   void reserve(std::size_t n, std::size_t keep = 0, hipStream_t stream = nullptr) {
     if (n <= cap_)
       return;
-    error::throw_if_exception(!owns_, "caller-provided frontier storage is too small");
+    error::throw_if_exception(!owns_, "caller-provided frontier storage is too small: need " +
+                                          std::to_string(n) + " elements, have " +
+                                          std::to_string(cap_));
     type_t* fresh = memory::allocate<type_t>(n * sizeof(type_t));
     if (ptr_ && keep) {
       GRX_HIP_CHECK(hipMemcpyAsync(fresh, ptr_, keep * sizeof(type_t), hipMemcpyDeviceToDevice, stream));
