@@ -95,20 +95,26 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
+    # GRX_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU
+    backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = ea.Context(local_rank)
+    ctx = ea.Context(device)
     lb = ea.LoadBalance[a.lb]
     opts = ea.Options(load_balance=lb)
 
     if world > 1:
         from essentials_amd.distributed import PartitionedRunner
-        runner = PartitionedRunner(ctx, dist, a.scale, a.edge_factor, a.seed, a.weight_seed)
+        runner = PartitionedRunner(ctx, dist, a.scale, a.edge_factor, a.seed, a.weight_seed, opts)
     else:
         from essentials_amd.distributed import SingleRunner
         runner = SingleRunner(ctx, a.scale, a.edge_factor, a.seed, a.weight_seed)
@@ -141,7 +147,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

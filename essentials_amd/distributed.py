@@ -212,6 +212,10 @@ class PartitionedTraversal:
                 recv = self._recv_big[: self.world * slot]
                 self._all_gather(recv, self.send[:slot])
                 collectives += 1
+                if recv.is_cuda:
+                    # the collective is ordered on torch's stream, the engine runs on its own:
+                    # make the gathered slots visible before admit (phase 1 is fenced by .cpu())
+                    torch.cuda.current_stream().synchronize()
             n_cur, total = self.k.admit(op, labels, self.stamp, rounds, recv, self.world, slot,
                                         self.rank, self.lo, self.hi, nxt)
             found_total += total

@@ -91,21 +91,22 @@ def _rank(rank, world, port, scale, out_dir):
                                                       C.byref(hi)), "partition")
     local = ea.Graph(h)
     notes = []
-    for lb in (ea.LoadBalance.block_mapped, ea.LoadBalance.merge_path):
+    for lb, small_slot in ((ea.LoadBalance.block_mapped, None), (ea.LoadBalance.block_mapped, 64),
+                           (ea.LoadBalance.merge_path, None), (ea.LoadBalance.merge_path, 64)):
         trav = PartitionedTraversal(HipKernels(ctx, local, ea.Options(load_balance=lb)), dist, rank,
                                     world, full.n_rows, lo.value, hi.value, local.nnz, "cuda:0",
-                                    small_slot=64 if lb == ea.LoadBalance.merge_path else None)
+                                    small_slot=small_slot)
         for s in (0, 1830):
             depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
             trav.run(OP_BFS, s, depth)
             want, _ = o.bfs_heap(Ap, Aj, s)
             if not (depth.cpu().numpy() == want).all():
-                notes.append(f"bfs {s} {lb}")
+                notes.append(f"bfs {s} {lb.name} {small_slot}")
             d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
             trav.run(OP_SSSP, s, d)
             wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
             if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
-                notes.append(f"sssp {s} {lb}")
+                notes.append(f"sssp {s} {lb.name} {small_slot}")
     open(os.path.join(out_dir, f"rank{rank}." + ("bad" if notes else "ok")), "w").write(str(notes))
     dist.barrier()
     dist.destroy_process_group()
