@@ -142,8 +142,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     edges = 0
+    trace = os.environ.get("GRX_BENCH_TRACE")
     for i in range(a.steps):
+        ts = time.perf_counter()
         edges += step(sources[a.warmup + i])
+        if trace and rank == 0:
+            print(f"[bench] step {i} source {sources[a.warmup + i]}: "
+                  f"{(time.perf_counter() - ts) * 1e3:.2f} ms {runner.detail()}", file=sys.stderr)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -153,6 +158,15 @@ def main():
 
     # ---- roofline of the dominant kernel (BFS advance), outside the timed region ----
     roof = runner.bfs_roofline(sources[a.warmup], lb)
+    # HBM traffic of the same kernels from the committed PMC passes (rocprofv3 cannot run inside
+    # the bench): profiles/latest_pmc.json, produced by the command recorded in it
+    pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    if world == 1 and a.scale == 22 and a.lb == "block_mapped" and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        roof["traffic"] = pmc["traffic_bytes_per_traversal"]
+        roof["traffic_note"] = ("bytes per traversal = (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 "
+                                "--pmc passes (profiles/latest_pmc.json); lower bound without the x2: %d"
+                                % pmc["traffic_bytes_per_traversal_lower_bound"])
     out = {
         "metric": "traversed edges/sec (MTEPS) BFS+SSSP on RMAT-%d" % a.scale,
         "value": edges / dt / 1e6,
