@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libgrx_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libgrx_ref_oracle.so")
+_REF_CLIENTS = os.path.join(_HERE, "_ref", "libgrx_ref_clients.so")
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -45,7 +46,7 @@ def build(force: bool = False) -> None:
     ):
         subprocess.check_call(["make", "-C", _HERE, "libgrx_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir(os.environ.get("GRX_REFERENCE_ROOT", "/root/reference")) and (
-        force or not os.path.exists(_REF)
+        force or not os.path.exists(_REF) or not os.path.exists(_REF_CLIENTS)
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -272,3 +273,44 @@ class RefOracle:
         d = np.empty(n, np.float32)
         ms = self.L.ref_sssp_cpu(n, Ap, _nz(Aj, np.int32), _nz(Ax, np.float32), source, d)
         return d, ms
+
+
+class RefClients:
+    """The reference's UNCHANGED bfs.hxx / sssp.hxx / pr.hxx compiled against this repository's
+    include/gunrock (oracle/ref_clients_driver.cpp -> oracle/_ref/libgrx_ref_clients.so).
+    Drop-in evidence for the GPU tests; takes torch device tensors."""
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(_REF_CLIENTS)
+
+    def __init__(self) -> None:
+        import torch  # noqa: F401  (one HIP runtime per process: torch's first)
+        L = C.CDLL(_REF_CLIENTS)
+        self.L = L
+        vp = C.c_void_p
+        L.refc_bfs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_float)]
+        L.refc_sssp.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_float)]
+        L.refc_pr.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_float, C.c_float, vp,
+                              C.POINTER(C.c_float)]
+
+    def bfs(self, ap, aj, ax, source, out):
+        ms = C.c_float()
+        rc = self.L.refc_bfs(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(), ax.data_ptr(),
+                             source, out.data_ptr(), ms)
+        assert rc == 0
+        return ms.value
+
+    def sssp(self, ap, aj, ax, source, out):
+        ms = C.c_float()
+        rc = self.L.refc_sssp(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(),
+                              ax.data_ptr(), source, out.data_ptr(), ms)
+        assert rc == 0
+        return ms.value
+
+    def pr(self, ap, aj, ax, alpha, tol, out):
+        ms = C.c_float()
+        rc = self.L.refc_pr(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(), ax.data_ptr(),
+                            alpha, tol, out.data_ptr(), ms)
+        assert rc == 0
+        return ms.value

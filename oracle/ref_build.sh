@@ -15,3 +15,17 @@ hipcc -x hip --cuda-host-only -std=c++17 -O3 -fPIC -shared \
   -DGRX_REF_SSSP_CPU="\"$ref/examples/algorithms/sssp/sssp_cpu.hxx\"" \
   "$here/ref_driver.cpp" -o "$out/libgrx_ref_oracle.so"
 echo "ref_build: built $out/libgrx_ref_oracle.so"
+
+# The reference's unchanged bfs.hxx / sssp.hxx / pr.hxx compiled against THIS repository's
+# include/gunrock for gfx950 (GPU tests load it when present).
+repo="$(cd "$here/.." && pwd)"
+if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
+  hipcc -x hip -std=c++17 -O3 --offload-arch=gfx950 -fPIC -shared \
+    -Wno-inconsistent-missing-override -Wno-unused-result \
+    -I "$repo/include" \
+    -DGRX_REF_BFS_HXX="\"$ref/include/gunrock/algorithms/bfs.hxx\"" \
+    -DGRX_REF_SSSP_HXX="\"$ref/include/gunrock/algorithms/sssp.hxx\"" \
+    -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
+    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients.so"
+  echo "ref_build: built $out/libgrx_ref_clients.so"
+fi

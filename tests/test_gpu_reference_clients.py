@@ -1,0 +1,77 @@
+"""The reference's own bfs.hxx / sssp.hxx / pr.hxx, UNCHANGED, running on this engine.
+
+oracle/_ref/libgrx_ref_clients.so is compiled in the build container from the reference headers
+where they lie (oracle/ref_build.sh) with this repository's include/ first on the include path;
+it is a built artefact (never the reference's source) and is skipped when absent."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_graph
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def refc():
+    from oracle.oracle import RefClients
+    if not RefClients.available():
+        pytest.skip("oracle/_ref/libgrx_ref_clients.so not built (reference tree was not mounted)")
+    import torch
+    assert torch.cuda.is_available()
+    return RefClients()
+
+
+def dev(a, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def test_reference_bfs_sssp_headers_on_golden(refc, oracle, golden):
+    import torch
+    for name in ("chesapeake", "sample4x4", "tc4", "rmat8_w7", "rmat10_w7", "rmat12_w7", "rmat14_w0",
+                 "rmat10_directed"):
+        g = golden[name]
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        ap, aj, ax = dev(Ap), dev(Aj), dev(Ax)
+        for run in g["runs"]:
+            d = torch.empty(len(Ap) - 1, dtype=torch.int32, device="cuda")
+            refc.bfs(ap, aj, ax, run["source"], d)
+            assert sha(d.cpu().numpy()) == run["bfs_sha256"], (name, run["source"])
+            w = torch.empty(len(Ap) - 1, dtype=torch.float32, device="cuda")
+            refc.sssp(ap, aj, ax, run["source"], w)
+            assert sha(w.cpu().numpy().view(np.uint32)) == run["sssp_bits_sha256"], (name, run["source"])
+
+
+def test_reference_pr_header(refc, oracle):
+    import torch
+    n, Ap, Aj, Ax = oracle.rmat_csr(11, 8, 3, 0, False)
+    p = torch.empty(n, dtype=torch.float32, device="cuda")
+    refc.pr(dev(Ap), dev(Aj), dev(Ax), 0.85, 1e-6, p)
+    want, _ = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    assert np.abs(p.cpu().numpy() - want).max() < 5e-6   # parity unpinned in the reference
+
+
+def test_reference_bfs_header_rmat20(refc, oracle):
+    """Same engine, reference client: a graph big enough for hubs, chunks and several levels."""
+    import torch
+    import essentials_amd as ea
+    ctx = ea.Context(0)
+    g = ea.Graph.rmat(ctx, 20, 16, 1, 7)
+    Ap, Aj, Ax = g.to_host()
+    ap, aj, ax = dev(Ap), dev(Aj), dev(Ax)
+    d = torch.empty(g.n_rows, dtype=torch.int32, device="cuda")
+    ms = refc.bfs(ap, aj, ax, 0, d)
+    want, cpu_ms = oracle.bfs_heap(Ap, Aj, 0)
+    assert (d.cpu().numpy() == want).all()
+    mine, st = ea.bfs(ctx, g, 0)
+    assert torch.equal(mine, d)
+    print(f"reference bfs.hxx on this engine: {ms:.3f} ms; conformance client {st.elapsed_ms:.3f} ms; "
+          f"reference CPU checker port {cpu_ms:.0f} ms")
