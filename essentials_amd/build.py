@@ -94,6 +94,27 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     return LIB
 
 
+def build_cpp_tests(force: bool = False) -> list:
+    """tests/cpp/engine_tests (+ a build with the schedule override macro): C++-level checks of
+    the header surface, run by the GPU test suite."""
+    src = os.path.join(ROOT, "tests", "cpp", "engine_tests.hip")
+    outs = []
+    hdr_time = max(_newest(_headers()), os.path.getmtime(src))
+    jobs = []
+    for name, defs in (("engine_tests", []), ("engine_tests_override", ["-DGRX_ADVANCE_LB_OVERRIDE=bucketing"])):
+        out = os.path.join(ROOT, "tests", "cpp", name)
+        outs.append(out)
+        if force or not os.path.exists(out) or os.path.getmtime(out) < hdr_time:
+            jobs.append([HIPCC, "-x", "hip", "-std=c++17", "-O2", f"--offload-arch={ARCH}", "-I",
+                         os.path.join(ROOT, "include"), "-Wno-unused-result"] + defs + [src, "-o", out])
+    procs = [subprocess.Popen(j, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for j in jobs]
+    for pr, j in zip(procs, jobs):
+        _, err = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {j[-1]}:\n{err[-4000:]}")
+    return outs
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")

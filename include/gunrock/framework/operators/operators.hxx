@@ -3,3 +3,4 @@
 #include <gunrock/framework/operators/configs.hxx>
 #include <gunrock/framework/operators/advance.hxx>
 #include <gunrock/framework/operators/filter.hxx>
+#include <gunrock/framework/operators/batch.hxx>

@@ -540,8 +540,11 @@ int32_t orc_pagerank(int32_t n, const int32_t* Ap, const int32_t* Aj, const floa
     }
     if (max_iter > 0 && it >= max_iter) break;
     memcpy(plast, p, sizeof(float) * (size_t)n);
-    float dsum = 0;
-    for (int32_t v = 0; v < n; ++v) dsum += (iw[v] == 0) ? alpha * p[v] : 0;
+    /* the reference reduces with thrust::transform_reduce (a tree), not a running float: a
+     * sequential float32 sum of 1e7 terms of 1e-8 stagnates, so accumulate wide and round once */
+    double dacc = 0;
+    for (int32_t v = 0; v < n; ++v) dacc += (iw[v] == 0) ? (double)(alpha * p[v]) : 0.0;
+    float dsum = (float)dacc;
     float fill = (1 - alpha + dsum) / n;
     for (int32_t v = 0; v < n; ++v) p[v] = fill;
     for (int32_t v = 0; v < n; ++v) {

@@ -1,0 +1,288 @@
+// engine_tests.hip -- C++-level checks of the header surface that the C ABI does not reach:
+// frontier_t methods, parallel_for, enactor-overload operators (swap rules), explicit-frontier
+// advance (the form reference algorithms/bc.hxx:140-181 uses), batch, multi-context rejection,
+// and (when built with -DGRX_ADVANCE_LB_OVERRIDE=...) the schedule override.
+// Self-checking: expected values are computed by plain host loops below.  Exit code 0 = pass.
+#include <gunrock/algorithms/algorithms.hxx>
+#include <gunrock/hip/algorithms.hxx>
+
+#include <algorithm>
+#include <cstdio>
+#include <numeric>
+#include <set>
+#include <vector>
+
+using namespace gunrock;
+using vertex_t = int;
+using edge_t = int;
+using weight_t = float;
+
+static int failures = 0;
+#define CHECK(cond)                                                       \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);         \
+      ++failures;                                                         \
+    }                                                                     \
+  } while (0)
+
+struct host_graph {
+  int n;
+  std::vector<int> ap, aj;
+  std::vector<float> ax;
+};
+
+// deterministic pseudo-random multigraph with a hub (vertex 0) and isolated vertices
+static host_graph make_graph(int n, int avg) {
+  host_graph g;
+  g.n = n;
+  g.ap.assign(n + 1, 0);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+  std::vector<std::vector<int>> adj(n);
+  for (int v = 0; v < n; ++v) {
+    int d = (v == 0) ? std::min(n - 1, 5000) : (v % 7 == 3 ? 0 : (int)(rnd() % (2 * avg)));
+    for (int k = 0; k < d; ++k)
+      adj[v].push_back((int)(rnd() % n));
+  }
+  for (int v = 0; v < n; ++v) {
+    g.ap[v + 1] = g.ap[v] + (int)adj[v].size();
+    for (int c : adj[v]) { g.aj.push_back(c); g.ax.push_back(1.0f + (float)(c % 5)); }
+  }
+  return g;
+}
+
+template <typename T>
+static hip::device_array_t<T> upload(const std::vector<T>& h) {
+  hip::device_array_t<T> d;
+  d.assign(h.data(), h.size());
+  return d;
+}
+
+// a minimal problem/enactor pair so that the enactor overloads can be exercised
+template <typename graph_t>
+struct toy_problem_t : gunrock::problem_t<graph_t> {
+  using gunrock::problem_t<graph_t>::problem_t;
+  void init() override {}
+  void reset() override {}
+};
+template <typename problem_type>
+struct toy_enactor_t : gunrock::enactor_t<problem_type> {
+  using gunrock::enactor_t<problem_type>::enactor_t;
+  void loop(gcuda::multi_context_t&) override {}
+};
+
+int main() {
+  auto mc = std::make_shared<gcuda::multi_context_t>(0);
+  auto& ctx = *mc->get_context(0);
+  using frontier_t = frontier::frontier_t<vertex_t, edge_t>;
+
+  // ---- frontier_t -----------------------------------------------------------------------
+  {
+    frontier_t f;
+    CHECK(f.is_empty() && f.get_number_of_elements() == 0);
+    for (int i = 0; i < 200; ++i) f.push_back(i * 3);   // grows past its first allocation
+    auto h = f.to_host();
+    CHECK(h.size() == 200 && h[0] == 0 && h[199] == 597);
+    f.reserve(100000);                                  // contents survive a reserve
+    CHECK(f.get_capacity() >= 100000 && f.to_host() == h);
+    f.resize(210);                                      // new slots are invalid
+    h = f.to_host();
+    CHECK(h.size() == 210 && h[205] == -1 && h[199] == 597);
+    f.sequence(7, 1000, ctx.stream());
+    ctx.synchronize();
+    h = f.to_host();
+    CHECK(h.size() == 1000 && h[0] == 7 && h[999] == 1006);
+    f.fill(42, ctx.stream());
+    ctx.synchronize();
+    h = f.to_host();
+    CHECK(std::all_of(h.begin(), h.end(), [](int x) { return x == 42; }));
+    std::vector<int> mixed = {5, -1, 3, 9, 3, 0, 7};
+    frontier_t m;
+    for (int x : mixed) m.push_back(x);
+    m.sort(sort::order_t::ascending, ctx.stream());
+    std::sort(mixed.begin(), mixed.end());
+    CHECK(m.to_host() == mixed);
+    m.sort(sort::order_t::descending, ctx.stream());
+    std::reverse(mixed.begin(), mixed.end());
+    CHECK(m.to_host() == mixed);
+    CHECK(m.work_hint() == frontier_t::unknown_work);
+  }
+
+  host_graph hg = make_graph(20000, 12);
+  auto d_ap = upload(hg.ap);
+  auto d_aj = upload(hg.aj);
+  auto d_ax = upload(hg.ax);
+  auto G = graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+      hg.n, hg.n, (int)hg.aj.size(), d_ap.data(), d_aj.data(), d_ax.data());
+  using graph_t = decltype(G);
+  CHECK(G.get_number_of_vertices() == hg.n && G.get_number_of_edges() == (int)hg.aj.size());
+
+  // ---- parallel_for -----------------------------------------------------------------------
+  {
+    hip::device_array_t<int> deg(hg.n);
+    int* pdeg = deg.data();
+    auto per_vertex = [G, pdeg] __device__(vertex_t const& v) { pdeg[v] = G.get_number_of_neighbors(v); };
+    operators::parallel_for::execute<operators::parallel_for_each_t::vertex>(G, per_vertex, *mc);
+    auto h = deg.to_host();
+    bool ok = true;
+    for (int v = 0; v < hg.n; ++v) ok &= h[v] == hg.ap[v + 1] - hg.ap[v];
+    CHECK(ok);
+    hip::device_array_t<int> src(hg.aj.size());
+    int* psrc = src.data();
+    auto per_edge = [G, psrc] __device__(edge_t const& e) { psrc[e] = G.get_source_vertex(e); };
+    operators::parallel_for::execute<operators::parallel_for_each_t::edge>(G, per_edge, *mc);
+    auto hs = src.to_host();
+    ok = true;
+    for (int v = 0; v < hg.n; ++v)
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) ok &= hs[e] == v;
+    CHECK(ok);
+    hip::device_array_t<float> acc(1);
+    acc.zero();
+    float* pacc = acc.data();
+    auto per_weight = [pacc] __device__(weight_t const& w) { math::atomic::add(pacc, w); };
+    operators::parallel_for::execute<operators::parallel_for_each_t::weight>(G, per_weight, *mc);
+    CHECK(acc.to_host()[0] == std::accumulate(hg.ax.begin(), hg.ax.end(), 0.0f));  // small ints: exact
+    frontier_t f;
+    for (int x : {4, -1, 9, 4}) f.push_back(x);
+    hip::device_array_t<int> hits(hg.n);
+    hits.zero();
+    int* phits = hits.data();
+    auto per_elem = [phits] __device__(vertex_t const& v) { math::atomic::add(&phits[v], 1); };
+    operators::parallel_for::execute<operators::parallel_for_each_t::element>(f, per_elem, *mc);
+    auto hh = hits.to_host();
+    CHECK(hh[4] == 2 && hh[9] == 1 && std::accumulate(hh.begin(), hh.end(), 0) == 3);
+  }
+
+  // ---- explicit-frontier advance, every schedule, vertices->vertices and vertices->none --------
+  std::vector<int> fin_h;
+  for (int v = 0; v < hg.n; v += 3) fin_h.push_back(v);
+  fin_h.push_back(-1);
+  fin_h.push_back(0);  // the hub twice
+  std::vector<long long> want_hits(hg.n, 0);
+  std::multiset<int> want_out;
+  for (int v : fin_h) {
+    if (v < 0) continue;
+    for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) {
+      want_hits[hg.aj[e]] += 1;
+      if ((v + hg.aj[e]) % 2 == 0) want_out.insert(hg.aj[e]);
+    }
+  }
+  auto run_schedule = [&](auto lb_tag, const char* name) {
+    constexpr operators::load_balance_t lb = decltype(lb_tag)::value;
+    frontier_t fin, fout;
+    for (int v : fin_h) fin.push_back(v);
+    hip::device_array_t<int> hits(hg.n);
+    hits.zero();
+    int* ph = hits.data();
+    hip::device_array_t<edge_t> segments;
+    auto op = [ph] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                       weight_t const& w) -> bool {
+      math::atomic::add(&ph[d], 1);
+      return (s + d) % 2 == 0;
+    };
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::vertices>(G, op, &fin, &fout, segments, *mc);
+    auto out = fout.to_host();
+    std::multiset<int> got(out.begin(), out.end());
+    got.erase(-1);
+    auto hh = hits.to_host();
+    bool ok = true;
+    for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
+    if (!(ok && got == want_out)) { std::printf("FAIL schedule %s (vertices->vertices)\n", name); ++failures; }
+    CHECK(fout.work_hint() != frontier_t::unknown_work);
+    hits.zero();
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::none>(G, op, &fin, &fout, segments, *mc);
+    hh = hits.to_host();
+    ok = true;
+    for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
+    if (!ok) { std::printf("FAIL schedule %s (vertices->none)\n", name); ++failures; }
+  };
+  using lbt = operators::load_balance_t;
+  run_schedule(std::integral_constant<lbt, lbt::merge_path>(), "merge_path");
+  run_schedule(std::integral_constant<lbt, lbt::merge_path_v2>(), "merge_path_v2");
+  run_schedule(std::integral_constant<lbt, lbt::block_mapped>(), "block_mapped");
+  run_schedule(std::integral_constant<lbt, lbt::thread_mapped>(), "thread_mapped");
+  run_schedule(std::integral_constant<lbt, lbt::warp_mapped>(), "warp_mapped");
+  run_schedule(std::integral_constant<lbt, lbt::bucketing>(), "bucketing");
+  run_schedule(std::integral_constant<lbt, lbt::work_stealing>(), "work_stealing");
+
+  // ---- enactor overloads: which frontier is active afterwards ------------------------------
+  {
+    using problem_type = toy_problem_t<graph_t>;
+    problem_type P(G, mc);
+    toy_enactor_t<problem_type> E(&P, mc);
+    auto* in0 = E.get_input_frontier();
+    for (int x : {8, 2, 8, -1, 5, 2, 2}) in0->push_back(x);
+    auto odd_or_8 = [] __host__ __device__(vertex_t const& v) -> bool { return v == 8 || (v & 1); };
+    operators::filter::execute<operators::filter_algorithm_t::predicated>(G, &E, odd_or_8, *mc);
+    CHECK(E.get_input_frontier() != in0);                        // swapped
+    CHECK((E.get_input_frontier()->to_host() == std::vector<int>{8, 8, 5}));
+    operators::filter::execute<operators::filter_algorithm_t::bypass>(G, &E, odd_or_8, *mc, false);
+    CHECK((E.get_output_frontier()->to_host() == std::vector<int>{8, 8, 5}));  // no swap asked
+    auto* active = E.get_input_frontier();
+    for (int x : {1, 5, 1}) active->push_back(x);                // 8 8 5 1 5 1
+    operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *mc);
+    CHECK(E.get_input_frontier() == active);                     // in place: still the active one
+    CHECK((active->to_host() == std::vector<int>{1, 5, 8}));
+    for (int x : {8, 8, 9}) active->push_back(x);                // 1 5 8 8 8 9
+    operators::uniquify::execute<operators::uniquify_algorithm_t::unique_copy>(&E, *mc, true);
+    CHECK(E.get_input_frontier() != active);                     // copy variant swaps
+    CHECK((E.get_input_frontier()->to_host() == std::vector<int>{1, 5, 8, 9}));
+    bool threw = false;
+    try {
+      operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *mc, false, 150.0f);
+    } catch (error::exception_t&) { threw = true; }
+    CHECK(threw);
+  }
+
+  // ---- unsupported variants throw (reference advance.hxx:121-127) ---------------------------
+  {
+    frontier_t a, b;
+    a.push_back(1);
+    hip::device_array_t<edge_t> seg;
+    auto op = [] __host__ __device__(vertex_t const&, vertex_t const&, edge_t const&, weight_t const&) -> bool { return true; };
+    bool threw = false;
+    try {
+      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::backward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(G, op, &a, &b, seg, *mc);
+    } catch (error::exception_t&) { threw = true; }
+    CHECK(threw);
+    gcuda::multi_context_t two(std::vector<int>{0, 0});
+    threw = false;
+    try {
+      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(G, op, &a, &b, seg, two);
+    } catch (error::exception_t&) { threw = true; }
+    CHECK(threw);
+  }
+
+  // ---- batch: independent runs on host threads, each with its own context ---------------------
+  {
+    std::vector<int> degsum(12, 0);
+    auto job = [&](std::size_t j) -> float {
+      auto my = std::make_shared<gcuda::multi_context_t>(0);
+      frontier_t fin, fout;
+      fin.push_back((int)j);
+      hip::device_array_t<edge_t> seg;
+      auto op = [] __host__ __device__(vertex_t const&, vertex_t const&, edge_t const&, weight_t const&) -> bool { return true; };
+      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(G, op, &fin, &fout, seg, *my);
+      degsum[j] = (int)fout.get_number_of_elements();
+      return 1.0f;
+    };
+    float total = 0;
+    operators::batch::execute(job, degsum.size(), &total);
+    CHECK(total == (float)degsum.size());
+    for (std::size_t j = 0; j < degsum.size(); ++j) CHECK(degsum[j] == hg.ap[j + 1] - hg.ap[j]);
+  }
+
+  std::printf(failures ? "engine_tests: %d FAILURES\n" : "engine_tests: all passed\n", failures);
+  return failures ? 1 : 0;
+}
