@@ -330,3 +330,73 @@ def test_bfs_rmat22_properties(ea, ctx, torch):
     assert bool((best[nonsrc] + 1 == d0[nonsrc].long()).all())         # tight: parent exists
     assert st0.vertices_reached == int(reached.sum())
     assert st0.edges_traversed == int(deg[reached].sum())
+
+
+# ---------------------------------------------------------------------------
+# edge cases the reference's harness would hit (empty / degenerate inputs, bad arguments)
+# ---------------------------------------------------------------------------
+def test_degenerate_graphs(ea, ctx, torch):
+    # vertices but no edges
+    G = ea.Graph.from_host_csr(np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    assert G.n_rows == 5 and G.nnz == 0
+    for lb in ALL_LB:
+        d, st = ea.bfs(ctx, G, 3, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        assert host(d).tolist() == [INF_I, INF_I, INF_I, 0, INF_I]
+        assert st.iterations == 1 and st.edges_traversed == 0 and st.vertices_reached == 1
+        w, _ = ea.sssp(ctx, G, 3, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        assert host(w)[3] == 0 and host(w)[0] == INF_F
+    p, st = ea.pagerank(ctx, G, 0.85, 1e-6)
+    assert np.allclose(host(p), 0.2)                       # all dangling: uniform
+    # a single self loop
+    G = ea.Graph.from_host_csr(np.array([0, 1], np.int32), np.array([0], np.int32), np.ones(1, np.float32))
+    d, st = ea.bfs(ctx, G, 0)
+    assert host(d).tolist() == [0] and st.edges_traversed == 1
+    # a path: one vertex per level, many supersteps
+    n = 300
+    ap = np.concatenate([np.arange(n, dtype=np.int32), [n - 1]]).astype(np.int32)
+    aj = np.arange(1, n, dtype=np.int32)
+    G = ea.Graph.from_host_csr(ap, aj, np.full(n - 1, 2.0, np.float32))
+    d, st = ea.bfs(ctx, G, 0)
+    assert host(d).tolist() == list(range(n)) and st.iterations == n
+    w, _ = ea.sssp(ctx, G, 0, options=ea.Options(load_balance=ea.LoadBalance.merge_path))
+    assert host(w).tolist() == [2.0 * i for i in range(n)]
+    d, st = ea.bfs(ctx, G, 0, options=ea.Options(max_iterations=10))
+    assert st.iterations == 10 and host(d)[10] == 10 and host(d)[11] == INF_I
+
+
+def test_bad_arguments_are_errors(ea, ctx, torch, oracle):
+    n, Ap, Aj, Ax = oracle.rmat_csr(6, 4, 1, 0)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    with pytest.raises(ea.EngineError):
+        ea.bfs(ctx, G, -1)
+    with pytest.raises(ea.EngineError):
+        ea.sssp(ctx, G, n)
+    with pytest.raises(ea.EngineError):
+        ea.advance(ctx, G, None, ea.EdgeOp.bfs, None)       # functor needs its state
+    f = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(ea.EngineError):
+        ea.advance(ctx, G, f, ea.EdgeOp.all, options=ea.Options(load_balance=17))
+    with pytest.raises(ea.EngineError):
+        ea.Context(99)
+
+
+def test_independent_contexts_do_not_interfere(ea, torch, oracle):
+    """Two contexts (two streams) interleaved on one thread and two host threads at once
+    (the reference's operators::batch pattern)."""
+    import threading
+    n, Ap, Aj, Ax = oracle.rmat_csr(14, 16, 1, 7)
+    want, _ = oracle.bfs_heap(Ap, np.ascontiguousarray(Aj), 0)
+    results = {}
+
+    def work(k):
+        c = ea.Context(0)
+        g = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for _ in range(5):
+            d, _ = ea.bfs(c, g, 0)
+            results[k] = bool((host(d) == want).all())
+            if not results[k]:
+                return
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert results == {0: True, 1: True, 2: True, 3: True}
