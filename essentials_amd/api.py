@@ -68,14 +68,15 @@ class _Options(C.Structure):
     _fields_ = [("load_balance", C.c_int32), ("holes_layout", C.c_int32),
                 ("hub_threshold", C.c_int32), ("max_iterations", C.c_int32),
                 ("frontier_sizing_factor", C.c_float), ("collect_kernel_time", C.c_int32),
-                ("chunk_edges", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("chunk_edges", C.c_int32), ("direction_optimized", C.c_int32),
+                ("do_alpha", C.c_float), ("do_beta", C.c_float)]
 
 
 class _Stats(C.Structure):
     _fields_ = [("elapsed_ms", C.c_float), ("advance_kernel_ms", C.c_float),
                 ("iterations", C.c_int32), ("advance_launches", C.c_int32),
                 ("vertices_reached", C.c_int64), ("edges_traversed", C.c_int64),
-                ("levels_recorded", C.c_int32), ("reserved", C.c_int32),
+                ("levels_recorded", C.c_int32), ("pull_iterations", C.c_int32),
                 ("frontier_slots", C.c_int64 * 64)]
 
 
@@ -88,6 +89,9 @@ class Options:
     frontier_sizing_factor: float = 1.5
     collect_kernel_time: bool = False
     chunk_edges: int = 0
+    direction_optimized: bool = False
+    do_alpha: float = 0.0
+    do_beta: float = 0.0
 
     def _c(self) -> _Options:
         o = _Options()
@@ -98,6 +102,9 @@ class Options:
         o.frontier_sizing_factor = float(self.frontier_sizing_factor)
         o.collect_kernel_time = int(self.collect_kernel_time)
         o.chunk_edges = int(self.chunk_edges)
+        o.direction_optimized = int(self.direction_optimized)
+        o.do_alpha = float(self.do_alpha)
+        o.do_beta = float(self.do_beta)
         return o
 
 
@@ -110,12 +117,13 @@ class Stats:
     vertices_reached: int = 0
     edges_traversed: int = 0
     frontier_slots: list = field(default_factory=list)
+    pull_iterations: int = 0
 
     @staticmethod
     def _from(s: _Stats) -> "Stats":
         return Stats(s.elapsed_ms, s.advance_kernel_ms, s.iterations, s.advance_launches,
                      s.vertices_reached, s.edges_traversed,
-                     list(s.frontier_slots[: s.levels_recorded]))
+                     list(s.frontier_slots[: s.levels_recorded]), s.pull_iterations)
 
 
 # symbol -> (restype, argtypes); the list is also what tests check against the header

@@ -18,7 +18,6 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
     return with_load_balance(o.load_balance, [&](auto lb_tag) -> int {
       constexpr auto lb = decltype(lb_tag)::value;
       using problem_type = clients::bfs_problem_t<graph_type>;
-      using enactor_type = clients::bfs_enactor_t<problem_type, lb>;
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, source, d_distances, ctx->mc);
@@ -27,13 +26,27 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
       enactor_properties_t props;
       if (o.frontier_sizing_factor > 0)
         props.frontier_sizing_factor = o.frontier_sizing_factor;
-      enactor_type enactor(&problem, ctx->mc, props);
-      enactor.max_iterations = o.max_iterations;
-      const float ms = enactor.enact();
+      float ms = 0;
+      int iterations = 0, pulls = 0;
+      if (o.direction_optimized) {
+        clients::bfs_do_enactor_t<problem_type, lb> enactor(&problem, ctx->mc, props);
+        enactor.max_iterations = o.max_iterations;
+        if (o.do_alpha > 0) enactor.alpha = o.do_alpha;
+        if (o.do_beta > 0) enactor.beta = o.do_beta;
+        ms = enactor.enact();
+        iterations = enactor.iteration;
+        pulls = enactor.pull_iterations;
+      } else {
+        clients::bfs_enactor_t<problem_type, lb> enactor(&problem, ctx->mc, props);
+        enactor.max_iterations = o.max_iterations;
+        ms = enactor.enact();
+        iterations = enactor.iteration;
+      }
       if (stats) {
         std::memset(stats, 0, sizeof *stats);
+        stats->pull_iterations = pulls;
         stats->elapsed_ms = ms;
-        stats->iterations = enactor.iteration;
+        stats->iterations = iterations;
         stats->advance_kernel_ms = ctx->single().kernel_clock().total_ms;
         stats->advance_launches = ctx->single().kernel_clock().launches;
         stats->levels_recorded = problem.log.levels < 64 ? problem.log.levels : 64;

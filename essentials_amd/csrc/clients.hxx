@@ -107,6 +107,120 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
 };
 
 // ---------------------------------------------------------------------------
+// direction-optimising BFS (Beamer et al.): push while the frontier is small, PULL
+// (advance_direction_t::backward) while it is wide, push again for the tail.  Same
+// depths as the push-only search; new relative to the reference, whose advance
+// throws for the backward / optimized directions (configs.hxx:58-62).
+// Needs in-edges: an undirected (symmetric) CSR.
+// ---------------------------------------------------------------------------
+template <typename problem_type, load_balance_t lb>
+struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
+  using base_t = gunrock::enactor_t<problem_type>;
+  using vertex_t = typename problem_type::vertex_t;
+  using edge_t = typename problem_type::edge_t;
+  using weight_t = typename problem_type::weight_t;
+  using frontier_t = typename base_t::frontier_t;
+  int max_iterations = 0;
+  float alpha = 14.0f;  // pull when frontier edges > unexplored edges / alpha
+  float beta = 24.0f;   // push again when frontier vertices < |V| / beta
+  int pull_iterations = 0;
+
+  frontier_t candidates[2];  // still-unvisited vertices with at least one edge
+  int cand = 0;
+  bool have_candidates = false;
+  bool pulling = false;
+  hip::device_array_t<unsigned> in_frontier;  // one bit per vertex
+  unsigned long long unexplored = 0;          // edges out of unvisited vertices
+
+  bfs_do_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
+                   enactor_properties_t props = enactor_properties_t())
+      : base_t(p, ctx, props) {
+    auto g = p->get_graph();
+    in_frontier.resize(((std::size_t)g.get_number_of_vertices() + 31) / 32);
+    unexplored = (unsigned long long)g.get_number_of_edges();
+  }
+
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
+    f->push_back(this->get_problem()->source);
+  }
+
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (max_iterations && this->iteration >= max_iterations)
+      return true;
+    return base_t::is_converged(context);
+  }
+
+  void loop(gcuda::multi_context_t& context) override {
+    auto E = this->get_enactor();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    auto ctx = context.get_context(0);
+    frontier_t* in = E->get_input_frontier();
+    P->log.note(in->get_number_of_elements());
+
+    vertex_t* depth = P->depth;
+    const vertex_t next_level = this->iteration + 1;
+    const std::size_t n_vertices = (std::size_t)G.get_number_of_vertices();
+    const std::size_t n_f = in->get_number_of_elements();
+    const unsigned long long m_f = in->work_hint();
+
+    if (!pulling) {
+      if (m_f != frontier_t::unknown_work && (double)m_f > (double)unexplored / alpha)
+        pulling = true;
+    } else if ((double)n_f < (double)n_vertices / beta) {
+      pulling = false;
+    }
+
+    if (!pulling) {
+      auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                           edge_t const& edge,
+                                                           weight_t const& weight) -> bool {
+        return next_level < math::atomic::min(&depth[dst], next_level);
+      };
+      operators::advance::execute<lb>(G, E, visit, context);
+    } else {
+      ++pull_iterations;
+      // 1. candidates = unvisited vertices that have edges (built once, then only shrunk)
+      auto unvisited = [depth, G] __host__ __device__(vertex_t const& u) -> bool {
+        return depth[u] == std::numeric_limits<vertex_t>::max() && G.get_number_of_neighbors(u) > 0;
+      };
+      if (!have_candidates) {
+        candidates[cand].sequence(vertex_t(0), n_vertices, ctx->stream());
+        have_candidates = true;
+      }
+      operators::filter::execute<operators::filter_algorithm_t::predicated>(
+          G, unvisited, &candidates[cand], &candidates[cand ^ 1], context);
+      cand ^= 1;
+      // 2. membership bitmap of the current frontier
+      unsigned* bits = in_frontier.data();
+      in_frontier.zero(ctx->stream());
+      operators::parallel_for::execute<operators::parallel_for_each_t::element>(
+          *in, [bits] __device__(vertex_t const& v) { atomicOr(&bits[v >> 5], 1u << (v & 31)); },
+          context);
+      // 3. every candidate looks for a parent among its in-neighbours
+      auto adopt = [bits, depth, next_level] __host__ __device__(vertex_t const& parent,
+                                                                 vertex_t const& child,
+                                                                 edge_t const& edge,
+                                                                 weight_t const& weight) -> bool {
+        if ((bits[parent >> 5] >> (parent & 31)) & 1u) {
+          depth[child] = next_level;
+          return true;
+        }
+        return false;
+      };
+      operators::advance::execute<lb, operators::advance_direction_t::backward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(
+          G, adopt, &candidates[cand], E->get_output_frontier(), E->scanned_work_domain, context);
+      E->swap_frontier_buffers();
+    }
+    const unsigned long long found = E->get_input_frontier()->work_hint();
+    if (found != frontier_t::unknown_work)
+      unexplored = found < unexplored ? unexplored - found : 0;
+  }
+};
+
+// ---------------------------------------------------------------------------
 // single-source shortest paths (Bellman-Ford style frontier relaxation)
 // ---------------------------------------------------------------------------
 template <typename graph_t>

@@ -96,7 +96,10 @@ typedef struct grx_options {
   float frontier_sizing_factor; /* 0: default 1.5 (enactor.hxx:36)                                */
   int32_t collect_kernel_time;  /* 1: event-time the advance kernels (adds two events per launch)  */
   int32_t chunk_edges;          /* 0: default (1024): edges per chunk of a hub list                */
-  int32_t reserved[1];
+  int32_t direction_optimized;  /* grx_bfs only. 0: push every level (what bfs.hxx does); 1: pull the
+                                   wide levels (advance_direction_t::backward) -- undirected graphs */
+  float do_alpha;               /* 0: default 14: pull when frontier edges > unexplored edges/alpha  */
+  float do_beta;                /* 0: default 24: push again when frontier vertices < |V| / beta     */
 } grx_options;
 
 /* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the
@@ -109,7 +112,7 @@ typedef struct grx_stats {
   int64_t vertices_reached;    /* BFS/SSSP: labels != unreached                        */
   int64_t edges_traversed;     /* BFS/SSSP: sum of out-degrees of reached vertices     */
   int32_t levels_recorded;     /* min(iterations, 64)                                  */
-  int32_t reserved;
+  int32_t pull_iterations;     /* direction-optimised BFS: levels expanded by pulling   */
   int64_t frontier_slots[64];  /* input-frontier length of each iteration              */
 } grx_stats;
 

@@ -552,6 +552,73 @@ void execute(graph_t& G,
 }  // namespace bucketing
 
 // ===========================================================================
+// pull (advance_direction_t::backward): candidates in, newly hit candidates out
+// ===========================================================================
+namespace pull {
+
+/**
+ * @brief Pull advance.  `input` holds candidate DESTINATION vertices; for each one its
+ * in-edges are walked (CSR view of an undirected graph = its transpose) and
+ * op(in_neighbour, candidate, edge, weight) is called until it returns true; such
+ * candidates are written, packed, to `output`.  The op is called at most once per in-edge
+ * and never again for a candidate after its first true.  The reference declares this
+ * direction but throws for it (advance_direction_t::backward / optimized,
+ * framework/operators/configs.hxx:58-62, advance/merge_path.hxx:41-56).
+ */
+template <advance_io_type_t input_type,
+          advance_io_type_t output_type,
+          typename graph_t,
+          typename operator_t,
+          typename frontier_t>
+void execute(graph_t& G,
+             operator_t op,
+             frontier_t& input,
+             frontier_t& output,
+             gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using vertex_t = typename graph_t::vertex_type;
+  constexpr bool has_out = (output_type != advance_io_type_t::none);
+  error::throw_if_exception(G.is_directed(),
+                            "pull advance needs in-edges: the graph is marked directed and has no "
+                            "csc view (set G.properties.directed = false for a symmetric CSR)");
+  error::throw_if_exception(input_type != advance_io_type_t::vertices,
+                            "pull advance takes a vertex frontier of candidates");
+  const std::size_t n_in = input.get_number_of_elements();
+  if (n_in == 0) {
+    if (has_out)
+      output.set_number_of_elements(0);
+    return;
+  }
+  if (has_out && output.get_capacity() < n_in)
+    output.reserve(n_in);  // at most every candidate is emitted once
+  detail::clear_counters(context);
+  auto& ws = context.workspace();
+  unsigned long long* counters = ws.counters();
+  auto* long_queue = reinterpret_cast<k::resume_t<vertex_t>*>(
+      ws.queue(n_in * sizeof(k::resume_t<vertex_t>)));
+  vertex_t* out_ptr = has_out ? output.data() : nullptr;
+  const std::size_t capacity = has_out ? output.get_capacity() : 0;
+  const unsigned persistent = (unsigned)context.compute_units() * 8u;
+  detail::clocked_t clock(context);
+  k::pull_probe_kernel<output_type>
+      <<<detail::grid_for(n_in, k::ADV_BLOCK, persistent), k::ADV_BLOCK, 0, context.stream()>>>(
+          G, op, input.data(), n_in, out_ptr, capacity, long_queue, (unsigned long long)n_in, counters);
+  k::pull_long_kernel<output_type>
+      <<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0, context.stream()>>>(
+          G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, counters);
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  if (has_out)
+    detail::finish_output(output, false, ~0ull, context);
+  else {
+    context.synchronize();
+    context.kernel_clock().collect();
+  }
+}
+
+}  // namespace pull
+
+// ===========================================================================
 // dispatch
 // ===========================================================================
 
@@ -573,8 +640,13 @@ void execute(graph_t& G,
              work_tiles_t& segments,
              gcuda::multi_context_t& context) {
   error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
-  error::throw_if_exception(direction != advance_direction_t::forward,
-                            "advance: only the forward (push) direction is implemented");
+  error::throw_if_exception(direction == advance_direction_t::optimized,
+                            "advance: the push/pull choice is the client's (see the direction-"
+                            "optimising BFS in essentials_amd/csrc/clients.hxx); ask for forward or backward");
+  if constexpr (direction == advance_direction_t::backward) {
+    pull::execute<input_type, output_type>(G, op, *input, *output, *context.get_context(0));
+    return;
+  }
   error::throw_if_exception(input_type == advance_io_type_t::edges ||
                                 output_type == advance_io_type_t::edges ||
                                 output_type == advance_io_type_t::graph,

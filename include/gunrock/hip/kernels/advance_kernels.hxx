@@ -704,6 +704,152 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
+// PULL (advance_direction_t::backward).  The input frontier holds CANDIDATE
+// destinations u (e.g. the still-unvisited vertices).  For each valid u the
+// in-edges of u are walked in order and op(v, u, e, w) is called with v the
+// in-neighbour, until the op returns true or the list ends; u is emitted when it
+// did.  (For an undirected graph the CSR view is its own transpose.)
+//   pull_probe_kernel : one lane per candidate, at most PULL_PROBES edges; a
+//                       candidate still undecided with edges left goes to the long
+//                       queue as (u, resume offset)
+//   pull_long_kernel  : one wavefront per queued candidate, 64 edges per step,
+//                       ballot early exit
+// On a power-law graph most candidates of a wide BFS level meet a frontier
+// neighbour within the first few probes: the label / bitmap lookups drop from one
+// per edge of the frontier to a few per unvisited vertex.
+// ---------------------------------------------------------------------------
+constexpr int PULL_PROBES = 16;
+
+template <typename vertex_t>
+struct resume_t {
+  vertex_t vertex;
+  int offset;
+};
+
+template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    pull_probe_kernel(graph_t G,
+                      op_t op,
+                      const vertex_t* __restrict__ candidates,
+                      std::size_t n_candidates,
+                      vertex_t* __restrict__ output,
+                      std::size_t capacity,
+                      resume_t<vertex_t>* long_queue,
+                      unsigned long long long_capacity,
+                      unsigned long long* counters) {
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
+
+  const std::size_t n_tiles = (n_candidates + ADV_BLOCK - 1) / ADV_BLOCK;
+  for (std::size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const std::size_t idx = tile * ADV_BLOCK + tid;
+    vertex_t u = gunrock::numeric_limits<vertex_t>::invalid();
+    edge_t first = 0;
+    edge_t deg = 0;
+    if (idx < n_candidates) {
+      u = candidates[idx];
+      if (util::limits::is_valid(u)) {
+        first = G.get_starting_edge(u);
+        deg = G.get_starting_edge(u + 1) - first;
+      }
+    }
+    bool hit = false;
+    edge_t r = 0;
+    const edge_t stop = deg < (edge_t)PULL_PROBES ? deg : (edge_t)PULL_PROBES;
+    for (; r < stop; ++r) {
+      edge_t e = first + r;
+      vertex_t v = G.get_destination_vertex(e);
+      weight_t w = G.get_edge_weight(e);
+      if (op(v, u, e, w)) {
+        hit = true;
+        break;
+      }
+    }
+    // undecided with edges left: hand over to a whole wavefront
+    const bool more = !hit && r < deg;
+    const unsigned long long mm = __ballot(more);
+    if (mm) {
+      unsigned long long base = 0;
+      if (lane == 0)
+        base = atomicAdd(&counters[C_CHUNKS], (unsigned long long)__popcll(mm));
+      base = __shfl(base, 0, wave_size);
+      if (more) {
+        const unsigned long long at = base + rank_in_mask(mm);
+        if (at < long_capacity)
+          long_queue[at] = resume_t<vertex_t>{u, (int)r};
+        else
+          counters[C_OVERFLOW] = 1ull;
+      }
+    }
+    if constexpr (HAS_OUT) {
+      unsigned dn = 0;
+      if (hit)
+        dn = (unsigned)deg;
+      wq.push(hit, u, dn, output, capacity, counters);
+    }
+  }
+  if constexpr (HAS_OUT)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    pull_long_kernel(graph_t G,
+                     op_t op,
+                     const resume_t<vertex_t>* __restrict__ long_queue,
+                     unsigned long long long_capacity,
+                     vertex_t* __restrict__ output,
+                     std::size_t capacity,
+                     unsigned long long* counters) {
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = tid / wave_size;
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
+
+  unsigned long long n = counters[C_CHUNKS];
+  if (n > long_capacity)
+    n = long_capacity;
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * ADV_WAVES;
+  for (unsigned long long q = (unsigned long long)blockIdx.x * ADV_WAVES + wave; q < n; q += n_waves) {
+    const resume_t<vertex_t> item = long_queue[q];
+    vertex_t u = item.vertex;
+    const edge_t first = G.get_starting_edge(u);
+    const edge_t deg = G.get_starting_edge(u + 1) - first;
+    bool found = false;
+    for (edge_t r0 = (edge_t)item.offset; r0 < deg && !found; r0 += wave_size) {
+      const edge_t r = r0 + lane;
+      bool hit = false;
+      if (r < deg) {
+        edge_t e = first + r;
+        vertex_t v = G.get_destination_vertex(e);
+        weight_t w = G.get_edge_weight(e);
+        hit = op(v, u, e, w);
+      }
+      found = __ballot(hit) != 0ull;  // wave-uniform
+    }
+    if constexpr (HAS_OUT) {
+      // lane 0 speaks for the wavefront
+      wq.push(found && lane == 0, u, found ? (unsigned)deg : 0u, output, capacity, counters);
+    }
+  }
+  if constexpr (HAS_OUT)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+// ---------------------------------------------------------------------------
 // bucketing: bin valid input slots by degree into three queues.
 //   small  (< BUCKET_SMALL)  -> thread-per-slot        (thread_mapped_kernel)
 //   medium (< hub_threshold) -> wavefront-per-slot     (wave_mapped_kernel)

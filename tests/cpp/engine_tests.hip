@@ -247,9 +247,19 @@ int main() {
     auto op = [] __host__ __device__(vertex_t const&, vertex_t const&, edge_t const&, weight_t const&) -> bool { return true; };
     bool threw = false;
     try {
-      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::backward,
+      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::optimized,
                                   operators::advance_io_type_t::vertices,
                                   operators::advance_io_type_t::vertices>(G, op, &a, &b, seg, *mc);
+    } catch (error::exception_t&) { threw = true; }
+    CHECK(threw);
+    // pull needs in-edges: a graph marked directed (and without a csc view) is refused
+    auto Gd = G;
+    Gd.properties.directed = true;
+    threw = false;
+    try {
+      operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::backward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(Gd, op, &a, &b, seg, *mc);
     } catch (error::exception_t&) { threw = true; }
     CHECK(threw);
     gcuda::multi_context_t two(std::vector<int>{0, 0});

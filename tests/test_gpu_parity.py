@@ -400,3 +400,40 @@ def test_independent_contexts_do_not_interfere(ea, torch, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert results == {0: True, 1: True, 2: True, 3: True}
+
+
+# ---------------------------------------------------------------------------
+# pull advance + direction-optimising BFS (new relative to the reference)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("lb", ["block_mapped", "merge_path"])
+def test_direction_optimized_bfs_matches_oracle(ea, ctx, oracle, golden, lb):
+    opts = ea.Options(load_balance=ea.LoadBalance[lb], direction_optimized=True)
+    for name, g in golden.items():
+        if name == "rmat10_directed" or name == "sample4x4":
+            continue                      # pull needs a symmetric CSR
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for run in g["runs"]:
+            d, st = ea.bfs(ctx, G, run["source"], options=opts)
+            assert sha(host(d)) == run["bfs_sha256"], (name, run["source"])
+            assert st.edges_traversed == run["edges_traversed"]
+    # forced pulling from the first possible level on, and never
+    n, Ap, Aj, Ax = oracle.rmat_csr(16, 16, 1, 0)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    want, _ = oracle.bfs_heap(Ap, np.ascontiguousarray(Aj), 5)
+    for alpha, beta in ((1e9, 1e9), (1e-9, 24.0), (14.0, 24.0), (2.0, 2.0)):
+        d, st = ea.bfs(ctx, G, 5, options=ea.Options(load_balance=ea.LoadBalance[lb],
+                                                      direction_optimized=True, do_alpha=alpha, do_beta=beta))
+        assert (host(d) == want).all(), (alpha, beta)
+        if alpha == 1e9:
+            assert st.pull_iterations >= 2
+        if alpha == 1e-9:
+            assert st.pull_iterations == 0
+
+
+def test_direction_optimized_bfs_rmat22(ea, ctx, torch):
+    g = ea.Graph.rmat(ctx, 22, 16, seed=1)
+    d0, st0 = ea.bfs(ctx, g, 0)
+    d1, st1 = ea.bfs(ctx, g, 0, options=ea.Options(direction_optimized=True))
+    assert torch.equal(d0, d1) and st1.pull_iterations >= 1
+    assert st1.edges_traversed == st0.edges_traversed
