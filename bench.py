@@ -205,6 +205,9 @@ def main():
         "roofline": roof,
         "detail": runner.detail(),
     }
+    if world == 1 and "bfs" in a.algo:
+        out["bfs_direction_optimized"] = runner.bfs_direction_optimized(
+            sources[a.warmup:a.warmup + min(a.steps, 8)], lb)
     if rank == 0:
         if not a.no_cpu_baseline:
             Ap, Aj, Ax = runner.host_csr()

@@ -113,6 +113,20 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
 // throws for the backward / optimized directions (configs.hxx:58-62).
 // Needs in-edges: an undirected (symmetric) CSR.
 // ---------------------------------------------------------------------------
+/// bits[v/64] bit v%64 = (label[v] == level): one coalesced pass, one ballot per wavefront.
+template <typename label_t>
+__global__ void __launch_bounds__(256)
+    level_bitmap_kernel(const label_t* label, std::size_t n, label_t level, unsigned long long* bits) {
+  const std::size_t padded = (n + 63) / 64 * 64;
+  for (std::size_t i = blockIdx.x * (std::size_t)256 + threadIdx.x; i < padded;
+       i += (std::size_t)gridDim.x * 256) {
+    const bool in = i < n && label[i] == level;
+    const unsigned long long m = __ballot(in);
+    if ((threadIdx.x & 63) == 0)
+      bits[i / 64] = m;
+  }
+}
+
 template <typename problem_type, load_balance_t lb>
 struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
   using base_t = gunrock::enactor_t<problem_type>;
@@ -121,22 +135,23 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
   using weight_t = typename problem_type::weight_t;
   using frontier_t = typename base_t::frontier_t;
   int max_iterations = 0;
-  float alpha = 14.0f;  // pull when frontier edges > unexplored edges / alpha
+  float alpha = 4.0f;   // pull when frontier edges > unexplored edges / alpha (swept on RMAT-22)
   float beta = 24.0f;   // push again when frontier vertices < |V| / beta
   int pull_iterations = 0;
 
   frontier_t candidates[2];  // still-unvisited vertices with at least one edge
   int cand = 0;
   bool have_candidates = false;
+  bool candidates_current = false;
   bool pulling = false;
-  hip::device_array_t<unsigned> in_frontier;  // one bit per vertex
-  unsigned long long unexplored = 0;          // edges out of unvisited vertices
+  hip::device_array_t<unsigned long long> in_frontier;  // one bit per vertex
+  unsigned long long unexplored = 0;                    // edges out of unvisited vertices
 
   bfs_do_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                    enactor_properties_t props = enactor_properties_t())
       : base_t(p, ctx, props) {
     auto g = p->get_graph();
-    in_frontier.resize(((std::size_t)g.get_number_of_vertices() + 31) / 32);
+    in_frontier.resize(((std::size_t)g.get_number_of_vertices() + 63) / 64);
     unexplored = (unsigned long long)g.get_number_of_edges();
   }
 
@@ -178,40 +193,50 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
         return next_level < math::atomic::min(&depth[dst], next_level);
       };
       operators::advance::execute<lb>(G, E, visit, context);
+      candidates_current = false;  // a push level visits vertices behind the candidates' back
     } else {
       ++pull_iterations;
-      // 1. candidates = unvisited vertices that have edges (built once, then only shrunk)
-      auto unvisited = [depth, G] __host__ __device__(vertex_t const& u) -> bool {
-        return depth[u] == std::numeric_limits<vertex_t>::max() && G.get_number_of_neighbors(u) > 0;
-      };
-      if (!have_candidates) {
-        candidates[cand].sequence(vertex_t(0), n_vertices, ctx->stream());
-        have_candidates = true;
+      // 1. candidates = unvisited vertices that have edges.  Built by one compaction when pulling
+      //    starts (or resumes after push levels); afterwards each pull level hands its rejects
+      //    over as the next level's candidates.
+      if (!candidates_current) {
+        auto unvisited = [depth, G] __host__ __device__(vertex_t const& u) -> bool {
+          return depth[u] == std::numeric_limits<vertex_t>::max() && G.get_number_of_neighbors(u) > 0;
+        };
+        if (!have_candidates) {
+          candidates[cand].sequence(vertex_t(0), n_vertices, ctx->stream());
+          have_candidates = true;
+        }
+        operators::filter::execute<operators::filter_algorithm_t::predicated>(
+            G, unvisited, &candidates[cand], &candidates[cand ^ 1], context);
+        cand ^= 1;
+        candidates_current = true;
       }
-      operators::filter::execute<operators::filter_algorithm_t::predicated>(
-          G, unvisited, &candidates[cand], &candidates[cand ^ 1], context);
-      cand ^= 1;
-      // 2. membership bitmap of the current frontier
-      unsigned* bits = in_frontier.data();
-      in_frontier.zero(ctx->stream());
-      operators::parallel_for::execute<operators::parallel_for_each_t::element>(
-          *in, [bits] __device__(vertex_t const& v) { atomicOr(&bits[v >> 5], 1u << (v & 31)); },
-          context);
+      // 2. membership bitmap of the current frontier (512 KB at 2^22 vertices: it lives in
+      //    every XCD's L2, unlike the 16 MB label array), built by one pass over the labels
+      unsigned long long* bits = in_frontier.data();
+      const vertex_t this_level = this->iteration;
+      {
+        std::size_t blocks = (n_vertices + 255) / 256;
+        const std::size_t cap = (std::size_t)ctx->compute_units() * 8;
+        level_bitmap_kernel<<<(unsigned)(blocks > cap ? cap : blocks), 256, 0, ctx->stream()>>>(
+            depth, n_vertices, this_level, bits);
+      }
       // 3. every candidate looks for a parent among its in-neighbours
       auto adopt = [bits, depth, next_level] __host__ __device__(vertex_t const& parent,
                                                                  vertex_t const& child,
                                                                  edge_t const& edge,
                                                                  weight_t const& weight) -> bool {
-        if ((bits[parent >> 5] >> (parent & 31)) & 1u) {
+        if ((bits[parent >> 6] >> (parent & 63)) & 1ull) {
           depth[child] = next_level;
           return true;
         }
         return false;
       };
-      operators::advance::execute<lb, operators::advance_direction_t::backward,
-                                  operators::advance_io_type_t::vertices,
-                                  operators::advance_io_type_t::vertices>(
-          G, adopt, &candidates[cand], E->get_output_frontier(), E->scanned_work_domain, context);
+      operators::advance::pull::execute<operators::advance_io_type_t::vertices,
+                                        operators::advance_io_type_t::vertices>(
+          G, adopt, candidates[cand], *E->get_output_frontier(), *ctx, &candidates[cand ^ 1]);
+      cand ^= 1;
       E->swap_frontier_buffers();
     }
     const unsigned long long found = E->get_input_frontier()->work_hint();

@@ -100,6 +100,28 @@ class SingleRunner:
                 "edges_traversed": best.edges_traversed, "vertices_reached": best.vertices_reached,
                 "kernel_gteps": best.edges_traversed / (best.advance_kernel_ms * 1e-3) / 1e9}
 
+    def bfs_direction_optimized(self, sources, lb) -> dict:
+        """SURVEY 8(f) rank 4 (beyond the reference, whose advance throws for pull): the same
+        traversals with the wide levels pulled.  Same depths; reported beside the headline."""
+        ms, edges, pulls = [], 0, 0
+        opts = ea.Options(load_balance=lb, direction_optimized=True)
+        for s in sources:
+            best = None
+            for _ in range(2):
+                _, st = ea.bfs(self.ctx, self.g, s, self.depth, opts)
+                if best is None or st.elapsed_ms < best.elapsed_ms:
+                    best = st
+            ms.append(best.elapsed_ms)
+            edges += best.edges_traversed
+            pulls += best.pull_iterations
+        total = sum(ms)
+        nbytes = 8 * edges + 20 * best.vertices_reached * len(sources)
+        return {"enact_ms_mean": total / len(ms), "mteps": edges / total / 1e3,
+                "pull_levels_mean": pulls / len(ms), "sources": len(sources),
+                "effective_algorithmic_gbps": nbytes / (total * 1e-3) / 1e9,
+                "note": "push levels: block_mapped; wide levels: pull (advance_direction_t::backward); "
+                        "edges counted as for the push search (out-degrees of reached vertices)"}
+
     def detail(self) -> dict:
         d = {}
         for k, st in self.last.items():

@@ -98,7 +98,7 @@ typedef struct grx_options {
   int32_t chunk_edges;          /* 0: default (1024): edges per chunk of a hub list                */
   int32_t direction_optimized;  /* grx_bfs only. 0: push every level (what bfs.hxx does); 1: pull the
                                    wide levels (advance_direction_t::backward) -- undirected graphs */
-  float do_alpha;               /* 0: default 14: pull when frontier edges > unexplored edges/alpha  */
+  float do_alpha;               /* 0: default 4: pull when frontier edges > unexplored edges/alpha   */
   float do_beta;                /* 0: default 24: push again when frontier vertices < |V| / beta     */
 } grx_options;
 

@@ -564,6 +564,10 @@ namespace pull {
  * and never again for a candidate after its first true.  The reference declares this
  * direction but throws for it (advance_direction_t::backward / optimized,
  * framework/operators/configs.hxx:58-62, advance/merge_path.hxx:41-56).
+ *
+ * `rejected` (optional): receives, packed, the candidates with at least one in-edge for which
+ * the op never returned true -- the candidate list of the next pull level, so that a caller
+ * alternating pull levels needs no separate compaction pass.
  */
 template <advance_io_type_t input_type,
           advance_io_type_t output_type,
@@ -574,7 +578,8 @@ void execute(graph_t& G,
              operator_t op,
              frontier_t& input,
              frontier_t& output,
-             gcuda::standard_context_t& context) {
+             gcuda::standard_context_t& context,
+             frontier_t* rejected = nullptr) {
   namespace k = detail::k;
   using vertex_t = typename graph_t::vertex_type;
   constexpr bool has_out = (output_type != advance_io_type_t::none);
@@ -591,6 +596,12 @@ void execute(graph_t& G,
   }
   if (has_out && output.get_capacity() < n_in)
     output.reserve(n_in);  // at most every candidate is emitted once
+  if (rejected) {
+    error::throw_if_exception(rejected->data() == input.data() && rejected->data() != nullptr,
+                              "pull advance: `rejected` must not alias the candidates");
+    if (rejected->get_capacity() < n_in)
+      rejected->reserve(n_in);
+  }
   detail::clear_counters(context);
   auto& ws = context.workspace();
   unsigned long long* counters = ws.counters();
@@ -600,12 +611,23 @@ void execute(graph_t& G,
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
   const unsigned persistent = (unsigned)context.compute_units() * 8u;
   detail::clocked_t clock(context);
-  k::pull_probe_kernel<output_type>
-      <<<detail::grid_for(n_in, k::ADV_BLOCK, persistent), k::ADV_BLOCK, 0, context.stream()>>>(
-          G, op, input.data(), n_in, out_ptr, capacity, long_queue, (unsigned long long)n_in, counters);
-  k::pull_long_kernel<output_type>
-      <<<(unsigned)context.compute_units() * 4u, k::ADV_BLOCK, 0, context.stream()>>>(
-          G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, counters);
+  const unsigned probe_grid = detail::grid_for(n_in, k::ADV_BLOCK, persistent);
+  const unsigned long_grid = (unsigned)context.compute_units() * 4u;
+  if (rejected) {
+    k::pull_probe_kernel<output_type, true><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, input.data(), n_in, out_ptr, capacity, rejected->data(), long_queue,
+        (unsigned long long)n_in, counters);
+    k::pull_long_kernel<output_type, true><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, rejected->data(),
+        (unsigned long long)n_in, counters);
+  } else {
+    k::pull_probe_kernel<output_type, false><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, input.data(), n_in, out_ptr, capacity, (vertex_t*)nullptr, long_queue,
+        (unsigned long long)n_in, counters);
+    k::pull_long_kernel<output_type, false><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, (vertex_t*)nullptr, 0ull,
+        counters);
+  }
   GRX_HIP_CHECK(hipGetLastError());
   clock.stop();
   if (has_out)
@@ -613,6 +635,11 @@ void execute(graph_t& G,
   else {
     context.synchronize();
     context.kernel_clock().collect();
+  }
+  if (rejected) {
+    rejected->set_number_of_elements((std::size_t)context.workspace().mirror()[k::C_BUCKET0]);
+    error::throw_if_exception(context.workspace().mirror()[k::C_OVERFLOW] != 0,
+                              "pull advance: rejected list overflow");
   }
 }
 

@@ -84,6 +84,7 @@ struct wave_queue_t {
   vertex_t* q;              // this wavefront's ADV_WQCAP entries in LDS
   unsigned fill;            // wave-uniform
   unsigned long long work;  // per lane: sum of degrees of the neighbours this lane emitted
+  int cursor = C_OUT;       // counter slot that hands out positions of the destination list
 
   __device__ __forceinline__ void flush(vertex_t* out, std::size_t capacity,
                                         unsigned long long* counters) {
@@ -92,7 +93,7 @@ struct wave_queue_t {
     const int lane = lane_id();
     unsigned long long base = 0;
     if (lane == 0)
-      base = atomicAdd(&counters[C_OUT], (unsigned long long)fill);
+      base = atomicAdd(&counters[cursor], (unsigned long long)fill);
     base = __shfl(base, 0, wave_size);
     for (unsigned j = lane; j < fill; j += wave_size) {
       if (base + j < capacity)
@@ -130,7 +131,7 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
   const unsigned long long wave_work = wave_sum(wq.work);
   if (lane == 0) {
     s_counts[wave] = wq.fill;
-    if (wave_work)
+    if (wave_work && wq.cursor == C_OUT)
       atomicAdd(&counters[C_NEXT_WORK], wave_work);
   }
   __syncthreads();
@@ -139,7 +140,7 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
 #pragma unroll
     for (int w = 0; w < ADV_WAVES; ++w)
       total += s_counts[w];
-    *s_base = total ? atomicAdd(&counters[C_OUT], (unsigned long long)total) : 0ull;
+    *s_base = total ? atomicAdd(&counters[wq.cursor], (unsigned long long)total) : 0ull;
   }
   __syncthreads();
   unsigned long long base = *s_base;
@@ -726,7 +727,29 @@ struct resume_t {
   int offset;
 };
 
-template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t>
+/// Append `value` of the lanes with `keep` to a global list: one atomic per wavefront.
+template <typename vertex_t>
+__device__ __forceinline__ void wave_append(bool keep, vertex_t value, vertex_t* list,
+                                            unsigned long long list_capacity,
+                                            unsigned long long* cursor,
+                                            unsigned long long* overflow) {
+  const unsigned long long m = __ballot(keep);
+  if (!m)
+    return;
+  unsigned long long base = 0;
+  if (lane_id() == 0)
+    base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+  base = __shfl(base, 0, wave_size);
+  if (keep) {
+    const unsigned long long at = base + rank_in_mask(m);
+    if (at < list_capacity)
+      list[at] = value;
+    else
+      *overflow = 1ull;
+  }
+}
+
+template <advance_io_type_t OUT, bool REJECTS, typename graph_t, typename op_t, typename vertex_t>
 __global__ void __launch_bounds__(ADV_BLOCK)
     pull_probe_kernel(graph_t G,
                       op_t op,
@@ -734,6 +757,7 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                       std::size_t n_candidates,
                       vertex_t* __restrict__ output,
                       std::size_t capacity,
+                      vertex_t* __restrict__ rejected,
                       resume_t<vertex_t>* long_queue,
                       unsigned long long long_capacity,
                       unsigned long long* counters) {
@@ -743,9 +767,12 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   __shared__ unsigned s_counts[ADV_WAVES];
   __shared__ unsigned long long s_base;
   __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+  __shared__ vertex_t s_rejects[REJECTS ? ADV_WAVES * ADV_WQCAP : 1];
   const int tid = threadIdx.x;
   const int lane = lane_id();
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
+  wave_queue_t<vertex_t> rq{s_rejects + (REJECTS ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull,
+                            C_BUCKET0};
 
   const std::size_t n_tiles = (n_candidates + ADV_BLOCK - 1) / ADV_BLOCK;
   for (std::size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -794,12 +821,19 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         dn = (unsigned)deg;
       wq.push(hit, u, dn, output, capacity, counters);
     }
+    if constexpr (REJECTS) {
+      // candidates whose whole list was walked without a hit stay candidates
+      const bool rejected_here = util::limits::is_valid(u) && !hit && !more && deg > 0;
+      rq.push(rejected_here, u, 0u, rejected, n_candidates, counters);
+    }
   }
   if constexpr (HAS_OUT)
     drain_block(wq, s_counts, &s_base, output, capacity, counters);
+  if constexpr (REJECTS)
+    drain_block(rq, s_counts, &s_base, rejected, n_candidates, counters);
 }
 
-template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t>
+template <advance_io_type_t OUT, bool REJECTS, typename graph_t, typename op_t, typename vertex_t>
 __global__ void __launch_bounds__(ADV_BLOCK)
     pull_long_kernel(graph_t G,
                      op_t op,
@@ -807,6 +841,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                      unsigned long long long_capacity,
                      vertex_t* __restrict__ output,
                      std::size_t capacity,
+                     vertex_t* __restrict__ rejected,
+                     unsigned long long rejected_capacity,
                      unsigned long long* counters) {
   using edge_t = typename graph_t::edge_type;
   using weight_t = typename graph_t::weight_type;
@@ -817,7 +853,9 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid / wave_size;
+  __shared__ vertex_t s_rejects[REJECTS ? ADV_WAVES * ADV_WQCAP : 1];
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
+  wave_queue_t<vertex_t> rq{s_rejects + (REJECTS ? wave * ADV_WQCAP : 0), 0u, 0ull, C_BUCKET0};
 
   unsigned long long n = counters[C_CHUNKS];
   if (n > long_capacity)
@@ -844,9 +882,13 @@ __global__ void __launch_bounds__(ADV_BLOCK)
       // lane 0 speaks for the wavefront
       wq.push(found && lane == 0, u, found ? (unsigned)deg : 0u, output, capacity, counters);
     }
+    if constexpr (REJECTS)
+      rq.push(!found && lane == 0, u, 0u, rejected, (std::size_t)rejected_capacity, counters);
   }
   if constexpr (HAS_OUT)
     drain_block(wq, s_counts, &s_base, output, capacity, counters);
+  if constexpr (REJECTS)
+    drain_block(rq, s_counts, &s_base, rejected, (std::size_t)rejected_capacity, counters);
 }
 
 // ---------------------------------------------------------------------------
