@@ -437,3 +437,22 @@ def test_direction_optimized_bfs_rmat22(ea, ctx, torch):
     d1, st1 = ea.bfs(ctx, g, 0, options=ea.Options(direction_optimized=True))
     assert torch.equal(d0, d1) and st1.pull_iterations >= 1
     assert st1.edges_traversed == st0.edges_traversed
+
+
+def test_sssp_fractional_weights_within_one_ulp(ea, ctx, torch, oracle):
+    """north_star: SSSP distances within 1 ULP.  With arbitrary float weights every candidate
+    distance is a left-to-right path sum and float addition is monotone, so the fix point is the
+    same as the reference checker's; the test allows 1 ULP and reports exact equality."""
+    rng = np.random.default_rng(4)
+    n, Ap, Aj, _ = oracle.rmat_csr(14, 16, 1, 0)
+    Aj = np.ascontiguousarray(Aj)
+    Ax = (rng.random(len(Aj)) * 9.9 + 0.1).astype(np.float32)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    for lb in ("block_mapped", "merge_path", "bucketing"):
+        w, _ = ea.sssp(ctx, G, 7217, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        want, _ = oracle.sssp_heap(Ap, Aj, Ax, 7217)
+        got = host(w)
+        finite = want < 3e38
+        assert ((got < 3e38) == finite).all()
+        ulp = np.abs(got[finite].view(np.int32).astype(np.int64) - want[finite].view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, (lb, int(ulp.max()))
