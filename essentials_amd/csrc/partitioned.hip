@@ -168,8 +168,6 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     unsigned long long* counters = ws.counters();
     GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
                                  sc.stream()));
-    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_OVERFLOW, 0, sizeof(unsigned long long),
-                                 sc.stream()));
     if (count) {
       const unsigned grid = (unsigned)std::min<int64_t>((count + 255) / 256,
                                                         (int64_t)sc.compute_units() * 8);
@@ -179,12 +177,13 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     }
     publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
     GRX_HIP_CHECK(hipGetLastError());
-    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), counters, 24 * sizeof(unsigned long long),
-                                 hipMemcpyDeviceToHost, sc.stream()));
+    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror() + hip::kernels::C_SELECT, counters + hip::kernels::C_SELECT,
+                                 sizeof(unsigned long long), hipMemcpyDeviceToHost, sc.stream()));
+    unsigned long long* m = operators::advance::detail::fetch_counters(sc);
     sc.synchronize();
-    error::throw_if_exception(ws.mirror()[hip::kernels::C_OVERFLOW] != 0,
+    error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_expand: send buffer too small (needs V + 1 words)");
-    *n_found = (int64_t)ws.mirror()[hip::kernels::C_SELECT];
+    *n_found = (int64_t)m[hip::kernels::C_SELECT];
     return (int)GRX_OK;
   });
 }
@@ -274,8 +273,7 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
   return guarded([&] {
     auto& sc = ctx->single();
     auto& ws = sc.workspace();
-    unsigned long long* counters = ws.counters();
-    GRX_HIP_CHECK(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned long long), sc.stream()));
+    unsigned long long* counters = ws.counters();  // zero between operators (see fetch_counters)
     const int64_t total = (int64_t)world * (slot - 1);
     const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
                                                       (int64_t)sc.compute_units() * 8);
@@ -293,12 +291,11 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
     GRX_HIP_CHECK(hipMemcpy2DAsync(heads.data(), sizeof(int64_t), d_recv, (std::size_t)slot * 8,
                                    sizeof(int64_t), (std::size_t)world, hipMemcpyDeviceToHost,
                                    sc.stream()));
-    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), counters, 8 * sizeof(unsigned long long),
-                                 hipMemcpyDeviceToHost, sc.stream()));
+    unsigned long long* m = operators::advance::detail::fetch_counters(sc);  // also waits for heads
     sc.synchronize();
-    error::throw_if_exception(ws.mirror()[hip::kernels::C_OVERFLOW] != 0,
+    error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_admit: next frontier capacity exceeded");
-    *n_next = (int64_t)ws.mirror()[hip::kernels::C_OUT];
+    *n_next = (int64_t)m[hip::kernels::C_OUT];
     if (n_total_found) {
       int64_t t = 0;
       for (auto h : heads)

@@ -26,6 +26,8 @@
 #include <gunrock/hip/kernels/advance_kernels.hxx>
 #include <gunrock/hip/primitives.hxx>
 
+#include <atomic>
+
 /// Compile-time override of the schedule hard-coded by a client header, e.g.
 /// -DGRX_ADVANCE_LB_OVERRIDE=bucketing to run the unchanged sssp.hxx (which
 /// spells block_mapped, algorithms/sssp.hxx:139) with degree bucketing.
@@ -50,17 +52,51 @@ inline unsigned grid_for(std::size_t items, std::size_t per_block, unsigned cap 
   return (unsigned)(g > cap ? cap : g);
 }
 
-inline void clear_counters(gcuda::standard_context_t& ctx) {
-  GRX_HIP_CHECK(hipMemsetAsync(ctx.workspace().counters(), 0, 12 * sizeof(unsigned long long),
-                               ctx.stream()));
+/**
+ * @brief Hand the device counters to the host WITHOUT a memcpy command, a memset command or a
+ * stream-synchronise call: a one-lane kernel copies the first 16 counters into the pinned
+ * mirror, zeroes them for the next operator and then stores a sequence number; the host spins
+ * on that word.  (The reference pays a thrust reduce + D2H + cudaStreamSynchronize + a
+ * cudaMalloc'ed cursor per advance: block_mapped.hxx:160-204.)  Invariant: counters 0..15 are
+ * zero whenever no operator is in flight.
+ */
+template <int header_only = 0>  // a template so that every translation unit may define it
+__global__ void publish_counters_kernel(unsigned long long* counters, unsigned long long* mirror,
+                                        unsigned long long sequence) {
+  const int i = threadIdx.x;
+  if (i < 16) {
+    mirror[i] = counters[i];
+    counters[i] = 0ull;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) {
+    __hip_atomic_store(&mirror[gcuda::workspace_t::sequence_slot], sequence, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-/// Copy the first 16 counters to the pinned mirror and wait for the stream.
+/// Kept for call sites that want the counters clean: they already are (see above).
+inline void clear_counters(gcuda::standard_context_t&) {}
+
+/// Publish the counters and wait for them; returns the pinned mirror.
 inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
   auto& ws = ctx.workspace();
-  GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror(), ws.counters(), 16 * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, ctx.stream()));
-  ctx.synchronize();
+  const unsigned long long seq = ws.next_sequence();
+  publish_counters_kernel<0><<<1, 64, 0, ctx.stream()>>>(ws.counters(), ws.mirror(), seq);
+  GRX_HIP_CHECK(hipGetLastError());
+  volatile unsigned long long* flag = ws.mirror() + gcuda::workspace_t::sequence_slot;
+  unsigned spins = 0;
+  while (*flag != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFu) == 0) {
+      // every ~100 us: make sure the stream is still healthy (a faulted kernel never publishes)
+      hipError_t st = hipStreamQuery(ctx.stream());
+      if (st != hipSuccess && st != hipErrorNotReady)
+        error::throw_if_exception(st, "operator kernels failed");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return ws.mirror();
 }
 
@@ -84,7 +120,6 @@ unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
   if (auto* f = ws.find_graph(key, n))
     return f->max_degree;
   unsigned long long* counters = ws.counters();
-  GRX_HIP_CHECK(hipMemsetAsync(counters + k::C_MAXDEG, 0, sizeof(unsigned long long), ctx.stream()));
   if (n) {
     k::max_degree_kernel<<<grid_for(n, k::ADV_BLOCK, 1024), k::ADV_BLOCK, 0, ctx.stream()>>>(
         G, counters);
@@ -251,7 +286,7 @@ void execute(graph_t& G,
   if (has_out)
     detail::finish_output(output, holes, total, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
 }
@@ -337,7 +372,7 @@ void execute(graph_t& G,
   if (has_out)
     detail::finish_output(output, holes, total, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
 }
@@ -409,7 +444,7 @@ void execute(graph_t& G,
   if (has_out)
     detail::finish_output(output, holes, total, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
 }
@@ -457,7 +492,7 @@ void execute(graph_t& G,
   if (has_out)
     detail::finish_output(output, false, total, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
 }
@@ -538,13 +573,14 @@ void execute(graph_t& G,
   if (n_chunks)
     k::chunk_kernel<output_type>
         <<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu, k::ADV_BLOCK, 0,
-           context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
+           context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr, capacity, counters,
+                               (long long)n_chunks);
   GRX_HIP_CHECK(hipGetLastError());
   clock.stop();
   if (has_out)
     detail::finish_output(output, false, total, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
 }
@@ -633,7 +669,7 @@ void execute(graph_t& G,
   if (has_out)
     detail::finish_output(output, false, ~0ull, context);
   else {
-    context.synchronize();
+    detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
   if (rejected) {

@@ -100,6 +100,9 @@ class workspace_t {
   }
   /// Pinned host mirror of the counters.
   unsigned long long* mirror() { return mirror_.data(); }
+  /// Slot of the mirror that carries the hand-off sequence number, and the next number.
+  static constexpr std::size_t sequence_slot = 31;
+  unsigned long long next_sequence() { return ++sequence_; }
 
   /// Growable untyped scratch (rocPRIM temp storage, block counts, flag words).
   void* scratch(std::size_t bytes) {
@@ -135,6 +138,7 @@ class workspace_t {
  private:
   hip::buffer_t<unsigned long long> counters_;
   hip::pinned_t<unsigned long long> mirror_{n_counters};
+  unsigned long long sequence_ = 0;
   hip::buffer_t<unsigned char> scratch_;
   hip::buffer_t<unsigned char> queue_;
   std::vector<graph_facts_t> graphs_;

@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                  unsigned long long chunk_capacity,
                  vertex_t* __restrict__ output,
                  std::size_t capacity,
-                 unsigned long long* counters) {
+                 unsigned long long* counters,
+                 long long known_chunks = -1) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   __shared__ unsigned s_counts[ADV_WAVES];
@@ -403,7 +404,10 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int tid = threadIdx.x;
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
 
-  unsigned long long n_chunks = counters[C_CHUNKS];
+  // the queue length: still in the device counter when this launch directly follows the
+  // producer, or passed by a host that already fetched (and thereby cleared) the counters
+  unsigned long long n_chunks = known_chunks >= 0 ? (unsigned long long)known_chunks
+                                                  : counters[C_CHUNKS];
   if (n_chunks > chunk_capacity)
     n_chunks = chunk_capacity;  // the overflowed tail was expanded in place
 
