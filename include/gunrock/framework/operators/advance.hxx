@@ -276,9 +276,14 @@ void execute(graph_t& G,
                                                       counters, chunks, chunk_capacity,
                                                       hub_threshold, chunk_edges);
     if (max_deg >= hub_threshold) {
-      k::chunk_kernel<output_type>
-          <<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu, k::ADV_BLOCK,
-             0, context.stream()>>>(G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
+      const unsigned chunk_grid =
+          (unsigned)context.compute_units() * context.options().chunk_blocks_per_cu;
+      if (context.options().wave_chunks)
+        k::wave_chunk_kernel<output_type><<<chunk_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+            G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
+      else
+        k::chunk_kernel<output_type><<<chunk_grid, k::ADV_BLOCK, 0, context.stream()>>>(
+            G, op, chunks, chunk_capacity, out_ptr, capacity, counters);
     }
   }
   GRX_HIP_CHECK(hipGetLastError());

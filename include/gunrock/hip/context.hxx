@@ -157,6 +157,8 @@ struct operator_options_t {
   /// Persistent workgroups per CU for the tile / chunk kernels.
   unsigned tile_blocks_per_cu = 8;
   unsigned chunk_blocks_per_cu = 4;
+  /// Hub chunks are taken by single wavefronts instead of whole workgroups.
+  bool wave_chunks = false;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -256,6 +258,8 @@ class standard_context_t {
       options_.tile_blocks_per_cu = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_CHUNK_BLOCKS_PER_CU"))
       options_.chunk_blocks_per_cu = (unsigned)std::atoi(e);
+    if (const char* e = std::getenv("GRX_WAVE_CHUNKS"))
+      options_.wave_chunks = std::atoi(e) != 0;
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));
     GRX_HIP_CHECK(hipGetDeviceProperties(&props_, ordinal_));
     timer_ = std::make_unique<util::timer_t>(stream_);

@@ -448,6 +448,75 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
+// Hub chunks, wavefront-granular: every wavefront of the persistent grid takes one
+// chunk at a time (64 consecutive edges per step, ADV_UNROLL steps in flight), so a
+// chunk shorter than a workgroup's 1024-edge step wastes no lanes and the hub
+// threshold can drop to a wavefront's width.
+// ---------------------------------------------------------------------------
+template <advance_io_type_t OUT, typename graph_t, typename op_t, typename vertex_t, typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    wave_chunk_kernel(graph_t G,
+                      op_t op,
+                      const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
+                      unsigned long long chunk_capacity,
+                      vertex_t* __restrict__ output,
+                      std::size_t capacity,
+                      unsigned long long* counters,
+                      long long known_chunks = -1) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = tid / wave_size;
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
+
+  unsigned long long n_chunks = known_chunks >= 0 ? (unsigned long long)known_chunks
+                                                  : counters[C_CHUNKS];
+  if (n_chunks > chunk_capacity)
+    n_chunks = chunk_capacity;
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * ADV_WAVES;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * ADV_WAVES + wave; c < n_chunks;
+       c += n_waves) {
+    const chunk_t<vertex_t, edge_t> d = chunks[c];
+    vertex_t source = d.source;
+    for (int j0 = 0; j0 < d.count; j0 += wave_size * ADV_UNROLL) {
+      vertex_t nbr[ADV_UNROLL];
+      edge_t eid[ADV_UNROLL];
+      weight_t wgt[ADV_UNROLL];
+      bool live[ADV_UNROLL];
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        const int j = j0 + k * wave_size + lane;
+        live[k] = j < d.count;
+        if (live[k]) {
+          eid[k] = d.first + (edge_t)j;
+          nbr[k] = G.get_destination_vertex(eid[k]);
+          wgt[k] = G.get_edge_weight(eid[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        bool keep = false;
+        if (live[k])
+          keep = op(source, nbr[k], eid[k], wgt[k]);
+        if constexpr (HAS_OUT) {
+          unsigned dn = 0;
+          if (keep)
+            dn = (unsigned)G.get_number_of_neighbors(nbr[k]);
+          wq.push(keep, nbr[k], dn, output, capacity, counters);
+        }
+      }
+    }
+  }
+  if constexpr (HAS_OUT)
+    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+}
+
+// ---------------------------------------------------------------------------
 // thread_mapped: one lane per input slot (reference thread_mapped.hxx:59-95).
 // Packed output through the wavefront queue; holes output at segments[slot]+rank.
 // ---------------------------------------------------------------------------

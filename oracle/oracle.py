@@ -47,6 +47,7 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "libgrx_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir(os.environ.get("GRX_REFERENCE_ROOT", "/root/reference")) and (
         force or not os.path.exists(_REF) or not os.path.exists(_REF_CLIENTS)
+        or not os.path.exists(_REF_CLIENTS.replace(".so", "_bucketing.so"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -281,12 +282,16 @@ class RefClients:
     Drop-in evidence for the GPU tests; takes torch device tensors."""
 
     @staticmethod
-    def available() -> bool:
-        return os.path.exists(_REF_CLIENTS)
+    def available(variant: str = "") -> bool:
+        return os.path.exists(RefClients._path(variant))
 
-    def __init__(self) -> None:
+    @staticmethod
+    def _path(variant: str = "") -> str:
+        return _REF_CLIENTS if not variant else _REF_CLIENTS.replace(".so", f"_{variant}.so")
+
+    def __init__(self, variant: str = "") -> None:
         import torch  # noqa: F401  (one HIP runtime per process: torch's first)
-        L = C.CDLL(_REF_CLIENTS)
+        L = C.CDLL(self._path(variant))
         self.L = L
         vp = C.c_void_p
         L.refc_bfs.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_float)]

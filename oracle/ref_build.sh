@@ -28,4 +28,14 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
     -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
     "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients.so"
   echo "ref_build: built $out/libgrx_ref_clients.so"
+  # BASELINE config 3: the unchanged sssp.hxx (which spells block_mapped, sssp.hxx:139) run with
+  # the bucketing schedule through the documented compile-time override
+  hipcc -x hip -std=c++17 -O3 --offload-arch=gfx950 -fPIC -shared \
+    -Wno-inconsistent-missing-override -Wno-unused-result -DGRX_ADVANCE_LB_OVERRIDE=bucketing \
+    -I "$repo/include" \
+    -DGRX_REF_BFS_HXX="\"$ref/include/gunrock/algorithms/bfs.hxx\"" \
+    -DGRX_REF_SSSP_HXX="\"$ref/include/gunrock/algorithms/sssp.hxx\"" \
+    -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
+    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients_bucketing.so"
+  echo "ref_build: built $out/libgrx_ref_clients_bucketing.so"
 fi

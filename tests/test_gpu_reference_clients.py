@@ -75,3 +75,23 @@ def test_reference_bfs_header_rmat20(refc, oracle):
     assert torch.equal(mine, d)
     print(f"reference bfs.hxx on this engine: {ms:.3f} ms; conformance client {st.elapsed_ms:.3f} ms; "
           f"reference CPU checker port {cpu_ms:.0f} ms")
+
+
+def test_reference_sssp_header_with_bucketing_override(oracle, golden):
+    """BASELINE config 3: sssp.hxx unchanged + -DGRX_ADVANCE_LB_OVERRIDE=bucketing."""
+    import torch
+    from oracle.oracle import RefClients
+    if not RefClients.available("bucketing"):
+        pytest.skip("oracle/_ref/libgrx_ref_clients_bucketing.so not built")
+    rc = RefClients("bucketing")
+    for name in ("chesapeake", "rmat12_w7", "rmat14_w7"):
+        g = golden[name]
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        ap, aj, ax = dev(Ap), dev(Aj), dev(Ax)
+        for run in g["runs"]:
+            w = torch.empty(len(Ap) - 1, dtype=torch.float32, device="cuda")
+            rc.sssp(ap, aj, ax, run["source"], w)
+            assert sha(w.cpu().numpy().view(np.uint32)) == run["sssp_bits_sha256"], (name, run["source"])
+            d = torch.empty(len(Ap) - 1, dtype=torch.int32, device="cuda")
+            rc.bfs(ap, aj, ax, run["source"], d)
+            assert sha(d.cpu().numpy()) == run["bfs_sha256"], (name, run["source"])
