@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256)
 /// Pack the finds of one superstep, ONE pair per vertex (a vertex improved several times
 /// appears several times in the raw output): send[1 + k] = (vertex | label bits << 32), the
 /// label read after the advance, i.e. the best this rank knows.  counters[C_SELECT] counts them.
-template <typename label_t>
+template <typename label_t, bool DEDUPE>
 __global__ void __launch_bounds__(256)
     pack_pairs_kernel(const int32_t* found, int64_t count, const label_t* labels, int32_t* sent,
                       int32_t round, int64_t* send, int64_t send_capacity,
@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(256)
     int32_t v = -1;
     if (i < count) {
       v = found[i];
-      first = atomicExch(&sent[v], round) != round;  // exactly one packer per vertex and round
+      // SSSP may improve a vertex several times in one superstep: exactly one packer per vertex
+      // and round.  A BFS level discovers a vertex once per rank (atomic::min), no test needed.
+      first = DEDUPE ? (atomicExch(&sent[v], round) != round) : true;
     }
     const unsigned long long m = __ballot(first);
     if (m) {
@@ -72,7 +74,7 @@ __global__ void publish_count_kernel(int64_t* send, const unsigned long long* co
   send[0] = (int64_t)counters[hip::kernels::C_SELECT];
 }
 
-template <typename label_t>
+template <typename label_t, bool DEDUPE>
 __global__ void __launch_bounds__(256)
     admit_kernel(label_t* labels, int32_t* stamp, int32_t round, const int64_t* recv, int32_t world,
                  int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* next,
@@ -104,7 +106,9 @@ __global__ void __launch_bounds__(256)
         // exactly one copy per superstep (the reference's SSSP bypass predicate,
         // sssp.hxx:126-136, tolerates duplicates; here the frontier stays duplicate-free so
         // that its work is bounded by the rank's edge count)
-        if (fresh && v >= lo && v < hi && atomicExch(&stamp[v], round) != round)
+        // BFS: every rank proposes the same label, so exactly one proposal is fresh (this
+        // rank's own, or the first one to win the atomic::min) -- no stamp needed
+        if (fresh && v >= lo && v < hi && (!DEDUPE || atomicExch(&stamp[v], round) != round))
           admit = true;
       }
     }
@@ -140,6 +144,9 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     graph_type G = local->view();
     auto fin = frontier_type::wrap(const_cast<int32_t*>(d_frontier), (std::size_t)n_frontier,
                                    (std::size_t)(n_frontier ? n_frontier : 1));
+    // the owned frontier is duplicate-free (admit_kernel), so its work is bounded by the rank's
+    // edge count: no sizing pass
+    fin.set_work_hint((unsigned long long)local->nnz);
     auto fout = frontier_type::wrap(d_scratch, 0, (std::size_t)scratch_capacity);
     hip::device_array_t<edge_t> segments;
     if (edge_op == GRX_OP_BFS) {
@@ -171,16 +178,18 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     if (count) {
       const unsigned grid = (unsigned)std::min<int64_t>((count + 255) / 256,
                                                         (int64_t)sc.compute_units() * 8);
-      pack_pairs_kernel<label_t><<<grid, 256, 0, sc.stream()>>>(d_scratch, count, labels, d_sent,
-                                                                iparam, d_send, send_capacity,
-                                                                counters);
+      if (edge_op == GRX_OP_BFS)
+        pack_pairs_kernel<label_t, false><<<grid, 256, 0, sc.stream()>>>(
+            d_scratch, count, labels, d_sent, iparam, d_send, send_capacity, counters);
+      else
+        pack_pairs_kernel<label_t, true><<<grid, 256, 0, sc.stream()>>>(
+            d_scratch, count, labels, d_sent, iparam, d_send, send_capacity, counters);
     }
     publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
     GRX_HIP_CHECK(hipGetLastError());
     GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror() + hip::kernels::C_SELECT, counters + hip::kernels::C_SELECT,
                                  sizeof(unsigned long long), hipMemcpyDeviceToHost, sc.stream()));
-    unsigned long long* m = operators::advance::detail::fetch_counters(sc);
-    sc.synchronize();
+    unsigned long long* m = operators::advance::detail::fetch_counters(sc);  // follows the copy
     error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_expand: send buffer too small (needs V + 1 words)");
     *n_found = (int64_t)m[hip::kernels::C_SELECT];
@@ -278,25 +287,24 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
     const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
                                                       (int64_t)sc.compute_units() * 8);
     if (edge_op == GRX_OP_BFS)
-      admit_kernel<int32_t><<<grid, 256, 0, sc.stream()>>>(
+      admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
           (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
           (unsigned long long)next_capacity, counters);
     else
-      admit_kernel<float><<<grid, 256, 0, sc.stream()>>>(
+      admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
           (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
           (unsigned long long)next_capacity, counters);
     GRX_HIP_CHECK(hipGetLastError());
-    // the per-rank counts sit at recv[p * slot]: fetch them with the counters
-    std::vector<int64_t> heads((std::size_t)world);
-    GRX_HIP_CHECK(hipMemcpy2DAsync(heads.data(), sizeof(int64_t), d_recv, (std::size_t)slot * 8,
-                                   sizeof(int64_t), (std::size_t)world, hipMemcpyDeviceToHost,
-                                   sc.stream()));
-    unsigned long long* m = operators::advance::detail::fetch_counters(sc);  // also waits for heads
-    sc.synchronize();
+    unsigned long long* m = operators::advance::detail::fetch_counters(sc);
     error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_admit: next frontier capacity exceeded");
     *n_next = (int64_t)m[hip::kernels::C_OUT];
     if (n_total_found) {
+      // the per-rank counts sit at recv[p * slot]; the host loop already knows them from the
+      // gather, so this is only filled on request
+      std::vector<int64_t> heads((std::size_t)world);
+      GRX_HIP_CHECK(hipMemcpy2D(heads.data(), sizeof(int64_t), d_recv, (std::size_t)slot * 8,
+                                sizeof(int64_t), (std::size_t)world, hipMemcpyDeviceToHost));
       int64_t t = 0;
       for (auto h : heads)
         t += h;

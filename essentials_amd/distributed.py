@@ -20,6 +20,7 @@ rank knows from the first -- so most supersteps cost one collective and no count
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -151,12 +152,12 @@ class HipKernels:
         return n.value
 
     def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
-        n_next, total = C.c_int64(), C.c_int64()
+        n_next = C.c_int64()
         ea._check(self.lib.grx_partitioned_admit(
             self.ctx._h, op, labels.data_ptr(), stamp.data_ptr(), rnd, recv.data_ptr(), world, slot,
-            rank, lo, hi, nxt.data_ptr(), nxt.numel(), C.byref(n_next), C.byref(total)),
+            rank, lo, hi, nxt.data_ptr(), nxt.numel(), C.byref(n_next), None),
             "grx_partitioned_admit")
-        return n_next.value, total.value
+        return n_next.value
 
 
 class PartitionedTraversal:
@@ -215,8 +216,11 @@ class PartitionedTraversal:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         rounds = found_total = collectives = 0
+        prof = [0.0, 0.0, 0.0, 0.0] if os.environ.get("GRX_PART_PROFILE") else None
         while True:
+            ta = time.perf_counter()
             self.k.expand(op, labels, rounds, cur, n_cur, self.scratch, self.sent, self.send)
+            tb = time.perf_counter()
             slot = self.slot0
             recv = self.recv
             self._all_gather(recv, self.send[:slot])
@@ -224,6 +228,10 @@ class PartitionedTraversal:
             heads = recv.view(self.world, slot)[:, 0]
             counts = heads.cpu() if heads.is_cuda else heads
             most = int(counts.max())
+            tc = time.perf_counter()
+            if prof is not None:
+                prof[0] += tb - ta
+                prof[1] += tc - tb
             if most == 0:
                 break  # no rank improved anything: every replica is final
             if most > slot - 1:
@@ -238,15 +246,23 @@ class PartitionedTraversal:
                     # the collective is ordered on torch's stream, the engine runs on its own:
                     # make the gathered slots visible before admit (phase 1 is fenced by .cpu())
                     torch.cuda.current_stream().synchronize()
-            n_cur, total = self.k.admit(op, labels, self.stamp, rounds, recv, self.world, slot,
-                                        self.rank, self.lo, self.hi, nxt)
-            found_total += total
+            td = time.perf_counter()
+            n_cur = self.k.admit(op, labels, self.stamp, rounds, recv, self.world, slot,
+                                 self.rank, self.lo, self.hi, nxt)
+            found_total += int(counts.sum())
+            if prof is not None:
+                prof[2] += td - tc
+                prof[3] += time.perf_counter() - td
             cur, nxt = nxt, cur
             rounds += 1
         if labels.is_cuda:
             torch.cuda.synchronize()
-        return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
-                "pairs_exchanged": found_total, "collectives": collectives}
+        out = {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
+               "pairs_exchanged": found_total, "collectives": collectives}
+        if prof is not None:
+            out["profile_ms"] = {"expand": prof[0] * 1e3, "gather+counts": prof[1] * 1e3,
+                                 "big_gather": prof[2] * 1e3, "admit": prof[3] * 1e3}
+        return out
 
 
 class PartitionedRunner:

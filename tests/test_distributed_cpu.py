@@ -44,7 +44,7 @@ class NumpyKernels:
                 new = (iparam + 1) if op == OP_BFS else np.float32(lab[v] + self.ax[e])
                 if new < lab[d]:
                     lab[d] = new
-                    if snt[d] != iparam:        # packed once per vertex and superstep
+                    if op == OP_BFS or snt[d] != iparam:   # SSSP: packed once per vertex and superstep
                         snt[d] = iparam
                         found.append(d)
         s = send.numpy()
@@ -58,19 +58,19 @@ class NumpyKernels:
 
     def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
         lab, st, r, out = labels.numpy(), stamp.numpy(), recv.numpy().reshape(world, slot), nxt.numpy()
-        n, total = 0, 0
+        n = 0
         for p in range(world):
-            cnt = int(r[p, 0]); total += cnt
+            cnt = int(r[p, 0])
             for w in r[p, 1:1 + cnt]:
                 v = int(w & 0xFFFFFFFF)
                 l = np.array([(int(w) >> 32) & 0xFFFFFFFF], np.uint32).view(lab.dtype)[0]
                 fresh = True if p == rank else bool(l < lab[v])
                 if p != rank and fresh:
                     lab[v] = l
-                if fresh and lo <= v < hi and st[v] != rnd:
+                if fresh and lo <= v < hi and (op == OP_BFS or st[v] != rnd):
                     st[v] = rnd
                     out[n] = v; n += 1
-        return n, total
+        return n
 
 
 def _free_port():
