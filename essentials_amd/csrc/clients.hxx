@@ -113,20 +113,6 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
 // throws for the backward / optimized directions (configs.hxx:58-62).
 // Needs in-edges: an undirected (symmetric) CSR.
 // ---------------------------------------------------------------------------
-/// bits[v/64] bit v%64 = (label[v] == level): one coalesced pass, one ballot per wavefront.
-template <typename label_t>
-__global__ void __launch_bounds__(256)
-    level_bitmap_kernel(const label_t* label, std::size_t n, label_t level, unsigned long long* bits) {
-  const std::size_t padded = (n + 63) / 64 * 64;
-  for (std::size_t i = blockIdx.x * (std::size_t)256 + threadIdx.x; i < padded;
-       i += (std::size_t)gridDim.x * 256) {
-    const bool in = i < n && label[i] == level;
-    const unsigned long long m = __ballot(in);
-    if ((threadIdx.x & 63) == 0)
-      bits[i / 64] = m;
-  }
-}
-
 template <typename problem_type, load_balance_t lb>
 struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
   using base_t = gunrock::enactor_t<problem_type>;
@@ -144,14 +130,14 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
   bool have_candidates = false;
   bool candidates_current = false;
   bool pulling = false;
-  hip::device_array_t<unsigned long long> in_frontier;  // one bit per vertex
-  unsigned long long unexplored = 0;                    // edges out of unvisited vertices
+  frontier::bitmap_frontier_t<vertex_t> in_frontier;  // dense view of the current frontier
+  unsigned long long unexplored = 0;                  // edges out of unvisited vertices
 
   bfs_do_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                    enactor_properties_t props = enactor_properties_t())
       : base_t(p, ctx, props) {
     auto g = p->get_graph();
-    in_frontier.resize(((std::size_t)g.get_number_of_vertices() + 63) / 64);
+    in_frontier.resize((std::size_t)g.get_number_of_vertices());
     unexplored = (unsigned long long)g.get_number_of_edges();
   }
 
@@ -214,20 +200,16 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
       }
       // 2. membership bitmap of the current frontier (512 KB at 2^22 vertices: it lives in
       //    every XCD's L2, unlike the 16 MB label array), built by one pass over the labels
-      unsigned long long* bits = in_frontier.data();
       const vertex_t this_level = this->iteration;
-      {
-        std::size_t blocks = (n_vertices + 255) / 256;
-        const std::size_t cap = (std::size_t)ctx->compute_units() * 8;
-        level_bitmap_kernel<<<(unsigned)(blocks > cap ? cap : blocks), 256, 0, ctx->stream()>>>(
-            depth, n_vertices, this_level, bits);
-      }
+      in_frontier.assign_if(
+          [depth, this_level] __device__(std::size_t v) { return depth[v] == this_level; }, *ctx);
+      const frontier::bitmap_view_t bits = in_frontier.view();
       // 3. every candidate looks for a parent among its in-neighbours
       auto adopt = [bits, depth, next_level] __host__ __device__(vertex_t const& parent,
                                                                  vertex_t const& child,
                                                                  edge_t const& edge,
                                                                  weight_t const& weight) -> bool {
-        if ((bits[parent >> 6] >> (parent & 63)) & 1ull) {
+        if (bits.test((std::size_t)parent)) {
           depth[child] = next_level;
           return true;
         }

@@ -239,6 +239,31 @@ int main() {
     CHECK(threw);
   }
 
+  // ---- dense (bitmap) frontier view -----------------------------------------------------------
+  {
+    frontier::bitmap_frontier_t<vertex_t> bm(hg.n);
+    frontier_t f;
+    for (int x : {5, 64, -1, 5, 19999, 63, 128}) f.push_back(x);
+    bm.assign(f, ctx);
+    CHECK(bm.count(ctx) == 5);
+    frontier_t back;
+    bm.to_vector(back, ctx);
+    CHECK((back.to_host() == std::vector<int>{5, 63, 64, 128, 19999}));
+    bm.assign_if([] __device__(std::size_t v) { return v % 1000 == 7; }, ctx);
+    CHECK(bm.count(ctx) == 20);
+    bm.to_vector(back, ctx);
+    auto hb = back.to_host();
+    CHECK(hb.size() == 20 && hb[0] == 7 && hb[19] == 19007);
+    hip::device_array_t<int> probe(3);
+    int* pp = probe.data();
+    auto view = bm.view();
+    hip::for_each_index(3, [view, pp] __device__(std::size_t i) { pp[i] = view.test(i == 0 ? 7 : (i == 1 ? 8 : 19007)); }, ctx.stream());
+    ctx.synchronize();
+    CHECK((probe.to_host() == std::vector<int>{1, 0, 1}));
+    bm.clear(ctx);
+    CHECK(bm.count(ctx) == 0);
+  }
+
   // ---- unsupported variants throw (reference advance.hxx:121-127) ---------------------------
   {
     frontier_t a, b;
