@@ -1,110 +1,3 @@
-/**
- * @file enactor.hxx
- * @brief The bulk-synchronous driver: two frontiers, a scan workspace and the
- * `while (!is_converged) { loop(); ++iteration; }` host loop.
- *
- * Same surface as reference framework/enactor.hxx:31-54 (enactor_properties_t)
- * and :78-310 (enactor_t): get_problem / get_enactor / get_input_frontier /
- * get_output_frontier / swap_frontier_buffers / enact() -> milliseconds, virtuals
- * prepare_frontier, loop, is_converged, finalize; public members iteration,
- * context, scanned_work_domain, active_frontier, inactive_frontier.
- * enact() times with events on the context's stream, around the loop only
- * (enactor.hxx:245-253).
- */
+/** @file enactor.hxx  enactor_t / enactor_properties_t live in framework/bsp.hxx. */
 #pragma once
-
-#include <memory>
-#include <vector>
-
-#include <gunrock/framework/frontier.hxx>
-#include <gunrock/framework/problem.hxx>
-#include <gunrock/hip/context.hxx>
-
-namespace gunrock {
-
-struct enactor_properties_t {
-  /// Frontier buffers are reserved to factor * max(|E|, |V|) elements up front.
-  float frontier_sizing_factor{1.5f};
-  std::size_t number_of_frontier_buffers{2};
-  /// true: the enactor allocates no frontier storage (PageRank, pr.hxx:210-211).
-  bool self_manage_frontiers{false};
-};
-
-template <typename algorithm_problem_t,
-          frontier::frontier_kind_t frontier_kind = frontier::frontier_kind_t::vertex_frontier,
-          frontier::frontier_view_t frontier_view = frontier::frontier_view_t::vector>
-struct enactor_t {
-  using vertex_t = typename algorithm_problem_t::vertex_t;
-  using edge_t = typename algorithm_problem_t::edge_t;
-  using frontier_t = frontier::frontier_t<vertex_t, edge_t, frontier_kind, frontier_view>;
-
-  enactor_properties_t properties;
-  std::shared_ptr<gcuda::multi_context_t> context;
-  algorithm_problem_t* problem;
-  std::vector<frontier_t> frontiers;
-  hip::device_array_t<edge_t> scanned_work_domain;
-  frontier_t* active_frontier;
-  frontier_t* inactive_frontier;
-  int buffer_selector;
-  int iteration;
-
-  enactor_t(const enactor_t&) = delete;
-  enactor_t& operator=(const enactor_t&) = delete;
-
-  enactor_t(algorithm_problem_t* _problem,
-            std::shared_ptr<gcuda::multi_context_t> _context,
-            enactor_properties_t _properties = enactor_properties_t())
-      : properties(_properties),
-        context(std::move(_context)),
-        problem(_problem),
-        frontiers(properties.number_of_frontier_buffers < 2 ? 2
-                                                            : properties.number_of_frontier_buffers),
-        active_frontier(&frontiers[0]),
-        inactive_frontier(&frontiers[1]),
-        buffer_selector(0),
-        iteration(0) {
-    if (!properties.self_manage_frontiers) {
-      auto g = problem->get_graph();
-      const std::size_t e = (std::size_t)g.get_number_of_edges();
-      const std::size_t v = (std::size_t)g.get_number_of_vertices();
-      const std::size_t initial = e > v ? e : v;
-      for (auto& f : frontiers) {
-        f.set_resizing_factor(properties.frontier_sizing_factor);
-        f.reserve(initial);
-      }
-    }
-  }
-  virtual ~enactor_t() = default;
-
-  algorithm_problem_t* get_problem() { return problem; }
-  enactor_t* get_enactor() { return this; }
-  frontier_t* get_input_frontier() { return active_frontier; }
-  frontier_t* get_output_frontier() { return inactive_frontier; }
-
-  void swap_frontier_buffers() {
-    buffer_selector ^= 1;
-    active_frontier = &frontiers[buffer_selector];
-    inactive_frontier = &frontiers[buffer_selector ^ 1];
-  }
-
-  /// Run to convergence; returns the milliseconds spent in the loop.
-  float enact() {
-    auto single_context = context->get_context(0);
-    prepare_frontier(get_input_frontier(), *context);
-    auto& timer = single_context->timer();
-    timer.begin();
-    while (!is_converged(*context)) {
-      loop(*context);
-      ++iteration;
-    }
-    finalize(*context);
-    return timer.end();
-  }
-
-  virtual void loop(gcuda::multi_context_t& context) = 0;
-  virtual void prepare_frontier(frontier_t*, gcuda::multi_context_t&) {}
-  virtual bool is_converged(gcuda::multi_context_t&) { return active_frontier->is_empty(); }
-  virtual void finalize(gcuda::multi_context_t&) {}
-};
-
-}  // namespace gunrock
+#include <gunrock/framework/bsp.hxx>

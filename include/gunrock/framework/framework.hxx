@@ -2,6 +2,5 @@
 #pragma once
 #include <gunrock/framework/frontier.hxx>
 #include <gunrock/framework/bitmap_frontier.hxx>
-#include <gunrock/framework/problem.hxx>
-#include <gunrock/framework/enactor.hxx>
+#include <gunrock/framework/bsp.hxx>
 #include <gunrock/framework/operators/operators.hxx>

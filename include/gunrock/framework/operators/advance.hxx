@@ -76,9 +76,6 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
   }
 }
 
-/// Kept for call sites that want the counters clean: they already are (see above).
-inline void clear_counters(gcuda::standard_context_t&) {}
-
 /// Publish the counters and wait for them; returns the pinned mirror.
 inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
   auto& ws = ctx.workspace();
@@ -242,7 +239,6 @@ void execute(graph_t& G,
   }
   const bool holes = has_out && context.options().holes_layout;
   const unsigned long long max_deg = detail::max_degree(G, context);
-  detail::clear_counters(context);
   unsigned long long total = ~0ull;
   if (has_out) {
     if (!detail::size_output<input_type>(G, input, output, n_in, holes, total, context))
@@ -352,7 +348,6 @@ void execute(graph_t& G,
     return;
   }
   const bool holes = has_out && context.options().holes_layout;
-  detail::clear_counters(context);
   const unsigned long long total = scan_degrees<input_type>(G, input.data(), n_in, segments, context);
   if (total == 0) {
     if (has_out)
@@ -415,7 +410,6 @@ void execute(graph_t& G,
     return;
   }
   const bool holes = has_out && context.options().holes_layout;
-  detail::clear_counters(context);
   unsigned long long total = ~0ull;
   const edge_t* seg = nullptr;
   if (holes) {
@@ -480,7 +474,6 @@ void execute(graph_t& G,
       output.set_number_of_elements(0);
     return;
   }
-  detail::clear_counters(context);
   unsigned long long total = ~0ull;
   if (has_out) {
     if (!detail::size_output<input_type>(G, input, output, n_in, false, total, context))
@@ -533,7 +526,6 @@ void execute(graph_t& G,
       output.set_number_of_elements(0);
     return;
   }
-  detail::clear_counters(context);
   unsigned long long total = ~0ull;
   if (has_out) {
     if (!detail::size_output<input_type>(G, input, output, n_in, false, total, context))
@@ -643,7 +635,6 @@ void execute(graph_t& G,
     if (rejected->get_capacity() < n_in)
       rejected->reserve(n_in);
   }
-  detail::clear_counters(context);
   auto& ws = context.workspace();
   unsigned long long* counters = ws.counters();
   auto* long_queue = reinterpret_cast<k::resume_t<vertex_t>*>(
