@@ -146,6 +146,7 @@ _SIGNATURES = {
     "grx_graph_write_csr_file": (C.c_int, [_VP, C.c_char_p]),
     "grx_graph_rmat": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                  C.POINTER(_VP)]),
+    "grx_graph_sorted_rows": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     "grx_graph_destroy": (C.c_int, [_VP]),
     "grx_graph_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int64), C.POINTER(_VP), C.POINTER(_VP),
@@ -311,6 +312,13 @@ class Graph:
         h = _VP()
         _check(load_library().grx_graph_rmat(ctx._h, scale, edge_factor, seed, weight_seed,
                                              int(symmetrize), C.byref(h)), "grx_graph_rmat")
+        return Graph(h)
+
+    def sorted_rows(self, ctx: "Context") -> "Graph":
+        """Same graph, neighbour lists sorted by column id (SuiteSparse-style layout)."""
+        h = _VP()
+        _check(load_library().grx_graph_sorted_rows(ctx._h, self._h, C.byref(h)),
+               "grx_graph_sorted_rows")
         return Graph(h)
 
     def write_csr_file(self, path: str) -> None:

@@ -14,6 +14,8 @@
  */
 #include "capi_internal.hxx"
 
+#include <algorithm>
+
 using namespace essentials_amd;
 
 namespace {
@@ -140,6 +142,67 @@ std::unique_ptr<grx_graph_s> rmat_build(gcuda::standard_context_t& c, unsigned s
 }
 
 }  // namespace essentials_amd
+
+namespace {
+/// key[e] = (row << 32) | col for every edge: rows from the offsets by binary search
+__global__ void __launch_bounds__(256)
+    row_col_keys_kernel(const int* ap, const int* aj, int n_rows, long long nnz,
+                        unsigned long long* keys) {
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < nnz; e += (long long)gridDim.x * 256) {
+    int lo = 0, hi = n_rows;  // ap[lo] <= e < ap[hi]
+    while (hi - lo > 1) {
+      const int mid = lo + (hi - lo) / 2;
+      if ((long long)ap[mid] <= e)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    keys[e] = ((unsigned long long)(unsigned)lo << 32) | (unsigned)aj[e];
+  }
+}
+__global__ void __launch_bounds__(256)
+    keys_to_cols_kernel(const unsigned long long* keys, long long nnz, int* aj) {
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < nnz; e += (long long)gridDim.x * 256)
+    aj[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
+}
+}  // namespace
+
+extern "C" int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph_t* out) {
+  if (!ctx || !g || !out)
+    return invalid("grx_graph_sorted_rows: NULL argument");
+  return guarded([&] {
+    auto& c = ctx->single();
+    hipStream_t s = c.stream();
+    auto r = std::make_unique<grx_graph_s>();
+    r->n_rows = g->n_rows;
+    r->n_cols = g->n_cols;
+    r->nnz = g->nnz;
+    r->ap.resize((std::size_t)g->n_rows + 1);
+    r->aj.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+    r->ax.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+    GRX_HIP_CHECK(hipMemcpyAsync(r->ap.data(), g->d_ap, ((std::size_t)g->n_rows + 1) * 4,
+                                 hipMemcpyDeviceToDevice, s));
+    if (g->nnz) {
+      const std::size_t nnz = (std::size_t)g->nnz;
+      hip::buffer_t<unsigned long long> keys(nnz), keys2(nnz);
+      const unsigned grid = (unsigned)c.compute_units() * 8;
+      row_col_keys_kernel<<<grid, 256, 0, s>>>(g->d_ap, g->d_aj, g->n_rows, (long long)nnz, keys.data());
+      GRX_HIP_CHECK(hipGetLastError());
+      std::size_t bytes = 0;
+      GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys.data(), keys2.data(), g->d_ax,
+                                              r->ax.data(), nnz, 0, 64, s));
+      hip::buffer_t<unsigned char> temp(bytes);
+      GRX_HIP_CHECK(rocprim::radix_sort_pairs(temp.data(), bytes, keys.data(), keys2.data(), g->d_ax,
+                                              r->ax.data(), nnz, 0, 64, s));
+      keys_to_cols_kernel<<<grid, 256, 0, s>>>(keys2.data(), (long long)nnz, r->aj.data());
+      GRX_HIP_CHECK(hipGetLastError());
+    }
+    GRX_HIP_CHECK(hipStreamSynchronize(s));
+    r->adopt();
+    *out = r.release();
+    return (int)GRX_OK;
+  });
+}
 
 extern "C" int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_factor,
                               uint64_t seed, uint64_t weight_seed, int symmetrize,

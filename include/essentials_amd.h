@@ -148,6 +148,12 @@ int grx_graph_write_csr_file(grx_graph_t g, const char* path);
  * symmetrize != 0, weights 1.0f when weight_seed == 0 else integers in [1,64]. Built on the GPU. */
 int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_factor, uint64_t seed,
                    uint64_t weight_seed, int symmetrize, grx_graph_t* out);
+/* Copy of `g` whose neighbour lists are sorted by column id (duplicates adjacent, weights carried
+ * along): the layout a column-major-sorted Matrix Market file (SuiteSparse convention) gets from
+ * the reference's stable row sort (formats/csr.hxx:119-147).  The R-MAT generator above keeps the
+ * EMISSION order inside a row (an unsorted edge-list file); this utility produces the other
+ * common layout of the same graph. */
+int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph_t* out);
 int grx_graph_destroy(grx_graph_t g);
 int grx_graph_info(grx_graph_t g, int32_t* n_rows, int32_t* n_cols, int64_t* nnz,
                    const int32_t** d_row_offsets, const int32_t** d_col, const float** d_val);

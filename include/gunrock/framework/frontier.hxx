@@ -145,6 +145,9 @@ class frontier_t {
     if (num_elements_ + 1 > get_capacity())
       storage_->reserve(get_capacity() ? 2 * get_capacity() : 64, num_elements_);
     GRX_HIP_CHECK(hipMemcpy(data() + num_elements_, &value, sizeof(type_t), hipMemcpyHostToDevice));
+    // a small pageable H2D copy may return before it lands; operators run on a non-blocking
+    // stream that is not ordered after the null stream
+    GRX_HIP_CHECK(hipStreamSynchronize(nullptr));
     ++num_elements_;
     work_hint_ = unknown_work;
   }

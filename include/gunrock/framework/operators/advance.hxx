@@ -65,8 +65,9 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
                                         unsigned long long sequence) {
   const int i = threadIdx.x;
   if (i < 16) {
-    mirror[i] = counters[i];
-    counters[i] = 0ull;
+    // the counters were updated by device-scope atomics (memory side); read and clear them
+    // with cache-bypassing accesses instead of trusting what this XCD's L2 may still hold
+    mirror[i] = __hip_atomic_exchange(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __threadfence_system();
   __syncthreads();
@@ -123,6 +124,9 @@ unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
     GRX_HIP_CHECK(hipGetLastError());
   }
   unsigned long long md = fetch_counters(ctx)[k::C_MAXDEG];
+  if (std::getenv("GRX_DEBUG"))
+    std::fprintf(stderr, "[grx] max_degree(%zu vertices) = %llu (seq %llu)\n", n, md,
+                 ws.mirror()[gcuda::workspace_t::sequence_slot]);
   gcuda::workspace_t::graph_facts_t facts{key, n, md};
   return ws.remember_graph(facts)->max_degree;
 }
@@ -178,6 +182,9 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
                    gcuda::standard_context_t& ctx) {
   unsigned long long* m = fetch_counters(ctx);
   ctx.kernel_clock().collect();
+  if (std::getenv("GRX_DEBUG"))
+    std::fprintf(stderr, "[grx] advance done: out %llu chunks %llu next_work %llu\n", m[k::C_OUT],
+                 m[k::C_CHUNKS], m[k::C_NEXT_WORK]);
   error::throw_if_exception(m[k::C_OVERFLOW] != 0,
                             "advance: output frontier capacity exceeded");
   output.set_number_of_elements(holes ? (std::size_t)total : (std::size_t)m[k::C_OUT]);

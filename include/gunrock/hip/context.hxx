@@ -95,6 +95,9 @@ class workspace_t {
     if (!counters_.data()) {
       counters_.reserve(n_counters);
       GRX_HIP_CHECK(hipMemset(counters_.data(), 0, n_counters * sizeof(unsigned long long)));
+      // hipMemset on device memory may still be in flight when it returns, and the context's
+      // stream is non-blocking (not ordered after the null stream): wait once, here
+      GRX_HIP_CHECK(hipDeviceSynchronize());
     }
     return counters_.data();
   }

@@ -406,8 +406,10 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 
   // the queue length: still in the device counter when this launch directly follows the
   // producer, or passed by a host that already fetched (and thereby cleared) the counters
-  unsigned long long n_chunks = known_chunks >= 0 ? (unsigned long long)known_chunks
-                                                  : counters[C_CHUNKS];
+  unsigned long long n_chunks =
+      known_chunks >= 0 ? (unsigned long long)known_chunks
+                        : __hip_atomic_load(&counters[C_CHUNKS], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
   if (n_chunks > chunk_capacity)
     n_chunks = chunk_capacity;  // the overflowed tail was expanded in place
 
@@ -474,8 +476,10 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int wave = tid / wave_size;
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
 
-  unsigned long long n_chunks = known_chunks >= 0 ? (unsigned long long)known_chunks
-                                                  : counters[C_CHUNKS];
+  unsigned long long n_chunks =
+      known_chunks >= 0 ? (unsigned long long)known_chunks
+                        : __hip_atomic_load(&counters[C_CHUNKS], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
   if (n_chunks > chunk_capacity)
     n_chunks = chunk_capacity;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ADV_WAVES;
@@ -930,7 +934,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
   wave_queue_t<vertex_t> rq{s_rejects + (REJECTS ? wave * ADV_WQCAP : 0), 0u, 0ull, C_BUCKET0};
 
-  unsigned long long n = counters[C_CHUNKS];
+  unsigned long long n =
+      __hip_atomic_load(&counters[C_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n > long_capacity)
     n = long_capacity;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ADV_WAVES;

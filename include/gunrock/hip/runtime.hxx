@@ -231,8 +231,10 @@ class device_array_t {
   }
   void assign(const type_t* host, std::size_t n) {
     resize(n);
-    if (n)
+    if (n) {
       GRX_HIP_CHECK(hipMemcpy(buf_.data(), host, n * sizeof(type_t), hipMemcpyHostToDevice));
+      GRX_HIP_CHECK(hipStreamSynchronize(nullptr));  // see frontier_t::push_back
+    }
   }
   void assign(const std::vector<type_t>& host) { assign(host.data(), host.size()); }
   std::vector<type_t> to_host() const {

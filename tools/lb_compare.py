@@ -13,10 +13,13 @@ ap.add_argument("--algo", default="bfs,sssp")
 ap.add_argument("--source", type=int, default=0)
 ap.add_argument("--hub", default="0")
 ap.add_argument("--chunk", default="0")
+ap.add_argument("--sorted", action="store_true")
 a = ap.parse_args()
 ctx = ea.Context(0)
 g = ea.Graph.rmat(ctx, a.scale, 16, 1, 7)
-print(f"graph: V={g.n_rows} E={g.nnz}", flush=True)
+if a.sorted:
+    g = g.sorted_rows(ctx)
+print(f"graph: V={g.n_rows} E={g.nnz} sorted_rows={a.sorted}", flush=True)
 print("copy roof GB/s:", round(ctx.copy_bandwidth_gbps(1 << 30, 10), 1), flush=True)
 for algo in a.algo.split(","):
   fn = ea.bfs if algo == "bfs" else ea.sssp
