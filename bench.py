@@ -181,6 +181,7 @@ def main():
     if world == 1 and a.scale == 22 and a.lb == "block_mapped" and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         roof["traffic"] = pmc["traffic_bytes_per_traversal"]
+        roof["l2_busy_frac"] = pmc.get("l2", {}).get("busy_frac_all_bfs_advance_dispatches")
         roof["traffic_note"] = ("bytes per traversal = (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 "
                                 "--pmc passes (profiles/latest_pmc.json); lower bound without the x2: %d"
                                 % pmc["traffic_bytes_per_traversal_lower_bound"])
