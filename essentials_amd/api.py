@@ -69,7 +69,8 @@ class _Options(C.Structure):
                 ("hub_threshold", C.c_int32), ("max_iterations", C.c_int32),
                 ("frontier_sizing_factor", C.c_float), ("collect_kernel_time", C.c_int32),
                 ("chunk_edges", C.c_int32), ("direction_optimized", C.c_int32),
-                ("do_alpha", C.c_float), ("do_beta", C.c_float)]
+                ("do_alpha", C.c_float), ("do_beta", C.c_float),
+                ("chunk_queue_limit", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _Stats(C.Structure):
@@ -92,6 +93,7 @@ class Options:
     direction_optimized: bool = False
     do_alpha: float = 0.0
     do_beta: float = 0.0
+    chunk_queue_limit: int = 0
 
     def _c(self) -> _Options:
         o = _Options()
@@ -105,6 +107,7 @@ class Options:
         o.direction_optimized = int(self.direction_optimized)
         o.do_alpha = float(self.do_alpha)
         o.do_beta = float(self.do_beta)
+        o.chunk_queue_limit = int(self.chunk_queue_limit)
         return o
 
 

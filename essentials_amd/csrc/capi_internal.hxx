@@ -102,6 +102,7 @@ struct scoped_options {
       if (opt->chunk_edges > 0)
         ctx.options().chunk_edges = (unsigned)opt->chunk_edges;
       ctx.options().time_kernels = opt->collect_kernel_time != 0;
+      ctx.options().chunk_queue_limit = opt->chunk_queue_limit > 0 ? (unsigned long long)opt->chunk_queue_limit : 0ull;
     }
     ctx.kernel_clock().reset();
   }

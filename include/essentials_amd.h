@@ -100,6 +100,9 @@ typedef struct grx_options {
                                    wide levels (advance_direction_t::backward) -- undirected graphs */
   float do_alpha;               /* 0: default 4: pull when frontier edges > unexplored edges/alpha   */
   float do_beta;                /* 0: default 24: push again when frontier vertices < |V| / beta     */
+  int32_t chunk_queue_limit;    /* test hook, 0: none. Caps the hub chunk queue to force the overflow
+                                   path (hubs expanded in place)                                    */
+  int32_t reserved;
 } grx_options;
 
 /* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the

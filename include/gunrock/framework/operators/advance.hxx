@@ -208,6 +208,8 @@ k::chunk_t<vertex_t, edge_t>* chunk_queue(graph_t& G, std::size_t n_in, unsigned
     work_bound = (unsigned long long)G.get_number_of_edges() + (unsigned long long)n_in * hub;
   }
   capacity = work_bound / chunk_edges + hubs + 1024;
+  if (ctx.options().chunk_queue_limit && capacity > ctx.options().chunk_queue_limit)
+    capacity = ctx.options().chunk_queue_limit;
   return reinterpret_cast<k::chunk_t<vertex_t, edge_t>*>(
       ctx.workspace().queue(capacity * sizeof(k::chunk_t<vertex_t, edge_t>)));
 }

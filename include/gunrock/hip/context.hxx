@@ -162,6 +162,9 @@ struct operator_options_t {
   unsigned chunk_blocks_per_cu = 4;
   /// Hub chunks are taken by single wavefronts instead of whole workgroups.
   bool wave_chunks = false;
+  /// Test hook: cap the hub chunk queue (0 = sized per call) to force the overflow path, in
+  /// which a tile expands its hubs in place.
+  unsigned long long chunk_queue_limit = 0;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -263,6 +266,8 @@ class standard_context_t {
       options_.chunk_blocks_per_cu = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_WAVE_CHUNKS"))
       options_.wave_chunks = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))
+      options_.chunk_queue_limit = (unsigned long long)std::atoll(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));
     GRX_HIP_CHECK(hipGetDeviceProperties(&props_, ordinal_));
     timer_ = std::make_unique<util::timer_t>(stream_);

@@ -1027,8 +1027,10 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         deg = (unsigned)(G.get_starting_edge(v + 1) - first);
       }
     }
-    const bool is_small = deg > 0 && deg < BUCKET_SMALL;
-    bool is_medium = deg >= BUCKET_SMALL && deg < hub_threshold;
+    // three disjoint classes even when the hub threshold is set below BUCKET_SMALL
+    const unsigned small_limit = hub_threshold < BUCKET_SMALL ? hub_threshold : BUCKET_SMALL;
+    const bool is_small = deg > 0 && deg < small_limit;
+    bool is_medium = deg >= small_limit && deg < hub_threshold;
     // large lists: wave-aggregated chunk reservation
     const unsigned my_chunks = (deg >= hub_threshold) ? (deg + chunk_edges - 1) / chunk_edges : 0u;
     const unsigned incl = wave_inclusive_sum(my_chunks);

@@ -1,0 +1,90 @@
+"""Randomised parity sweeps and the rarely-taken paths of the advance kernels: tiny hub
+thresholds / chunk sizes, a capped chunk queue (overflow -> hubs expanded in place), output
+frontiers that must grow, many sources.  Everything is checked against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+INF_I = 2**31 - 1
+
+
+@pytest.fixture(scope="module")
+def env(oracle):
+    import torch
+    import essentials_amd as ea
+    assert torch.cuda.is_available()
+    return ea, ea.Context(0), torch
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("lb", ["block_mapped", "bucketing", "work_stealing"])
+def test_chunk_queue_overflow_falls_back_in_place(env, oracle, lb):
+    ea, ctx, torch = env
+    n, Ap, Aj, Ax = oracle.rmat_csr(13, 16, 3, 7)
+    Aj = np.ascontiguousarray(Aj)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    want, _ = oracle.bfs_heap(Ap, Aj, 0)
+    wantw, _ = oracle.sssp_heap(Ap, Aj, np.ascontiguousarray(Ax), 0)
+    for hub, chunk, limit in ((8, 4, 3), (16, 16, 1), (64, 64, 50), (2, 1, 7), (256, 1024, 2)):
+        o = ea.Options(load_balance=ea.LoadBalance[lb], hub_threshold=hub, chunk_edges=chunk,
+                       chunk_queue_limit=limit)
+        d, _ = ea.bfs(ctx, G, 0, options=o)
+        assert (host(d) == want).all(), (lb, hub, chunk, limit)
+        w, _ = ea.sssp(ctx, G, 0, options=o)
+        assert (host(w).view(np.uint32) == wantw.view(np.uint32)).all(), (lb, hub, chunk, limit)
+    # exactly-once per edge in the overflow path too
+    f = torch.arange(n, dtype=torch.int32, device="cuda")
+    calls = torch.zeros(len(Aj), dtype=torch.int32, device="cuda")
+    out = ea.advance(ctx, G, f, ea.EdgeOp.count_edge, calls, 0,
+                     ea.Options(load_balance=ea.LoadBalance[lb], hub_threshold=4, chunk_edges=2,
+                                chunk_queue_limit=5), capacity=len(Aj) + 16)
+    assert (host(calls) == 1).all()
+    src = np.repeat(np.arange(n), np.diff(Ap))
+    assert sorted(host(out).tolist()) == sorted(Aj[(src + Aj) % 3 == 0].tolist())
+
+
+def test_output_frontier_grows_when_needed(env, oracle):
+    """frontier_sizing_factor far too small: the engine must size the output exactly and grow it
+    (reference: block_mapped.hxx:171-173 reserve)."""
+    ea, ctx, torch = env
+    n, Ap, Aj, Ax = oracle.rmat_csr(12, 16, 1, 7)
+    G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+    want, _ = oracle.bfs_heap(Ap, np.ascontiguousarray(Aj), 0)
+    for lb in ("block_mapped", "merge_path", "bucketing", "thread_mapped"):
+        for holes in (False, True):
+            d, _ = ea.bfs(ctx, G, 0, options=ea.Options(load_balance=ea.LoadBalance[lb],
+                                                        frontier_sizing_factor=1e-6, holes_layout=holes))
+            assert (host(d) == want).all(), (lb, holes)
+
+
+def test_random_graphs_sources_schedules(env, oracle):
+    ea, ctx, torch = env
+    rng = np.random.default_rng(2026)
+    lbs = ["block_mapped", "merge_path", "bucketing", "work_stealing", "thread_mapped", "warp_mapped"]
+    for trial in range(12):
+        scale = int(rng.integers(5, 15))
+        ef = int(rng.integers(1, 24))
+        sym = bool(rng.integers(0, 2))
+        seed = int(rng.integers(1, 1 << 30))
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, seed, 7, sym)
+        Aj = np.ascontiguousarray(Aj); Ax = np.ascontiguousarray(Ax)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        for s in rng.integers(0, n, 2):
+            want, _ = oracle.bfs_heap(Ap, Aj, int(s))
+            wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, int(s))
+            lb = lbs[int(rng.integers(0, len(lbs)))]
+            o = ea.Options(load_balance=ea.LoadBalance[lb], holes_layout=bool(rng.integers(0, 2)),
+                           hub_threshold=int(rng.choice([2, 16, 256, 100000])),
+                           chunk_edges=int(rng.choice([1, 64, 1024])))
+            d, _ = ea.bfs(ctx, G, int(s), options=o)
+            assert (host(d) == want).all(), (trial, lb, s)
+            w, _ = ea.sssp(ctx, G, int(s), options=o)
+            assert (host(w).view(np.uint32) == wantw.view(np.uint32)).all(), (trial, lb, s)
+            if sym:
+                d2, _ = ea.bfs(ctx, G, int(s), options=ea.Options(direction_optimized=True,
+                                                                   do_alpha=float(rng.choice([0.5, 4, 1e6]))))
+                assert (host(d2) == want).all(), (trial, "do", s)
