@@ -150,6 +150,7 @@ _SIGNATURES = {
     "grx_graph_rmat": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                  C.POINTER(_VP)]),
     "grx_graph_sorted_rows": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    "grx_graph_build_in_edges": (C.c_int, [_VP, _VP]),
     "grx_graph_destroy": (C.c_int, [_VP]),
     "grx_graph_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int64), C.POINTER(_VP), C.POINTER(_VP),
@@ -323,6 +324,11 @@ class Graph:
         _check(load_library().grx_graph_sorted_rows(ctx._h, self._h, C.byref(h)),
                "grx_graph_sorted_rows")
         return Graph(h)
+
+    def build_in_edges(self, ctx: "Context") -> "Graph":
+        """Attach the transpose (in-edges) of a DIRECTED graph: enables pull / direction-optimised BFS."""
+        _check(load_library().grx_graph_build_in_edges(ctx._h, self._h), "grx_graph_build_in_edges")
+        return self
 
     def write_csr_file(self, path: str) -> None:
         _check(load_library().grx_graph_write_csr_file(self._h, path.encode()),

@@ -175,6 +175,19 @@ int grx_graph_write_csr_file(grx_graph_t g, const char* path) {
   });
 }
 
+int grx_graph_build_in_edges(grx_context_t ctx, grx_graph_t g) {
+  if (!ctx || !g)
+    return invalid("grx_graph_build_in_edges: NULL argument");
+  return guarded([&] {
+    if (g->in_edges)
+      return (int)GRX_OK;
+    graph_type G = g->view();
+    using T = graph::transposed_t<vertex_t, edge_t, weight_t>;
+    g->in_edges = std::make_unique<T>(graph::build::transpose(G, ctx->single()));
+    return (int)GRX_OK;
+  });
+}
+
 int grx_graph_destroy(grx_graph_t g) {
   if (!g)
     return GRX_OK;

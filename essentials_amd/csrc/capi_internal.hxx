@@ -74,12 +74,19 @@ struct grx_graph_s {
   const int32_t* d_ap = nullptr;
   const int32_t* d_aj = nullptr;
   const float* d_ax = nullptr;
+  // optional in-edge arrays (grx_graph_build_in_edges): marks the graph directed
+  std::unique_ptr<gunrock::graph::transposed_t<int32_t, int32_t, float>> in_edges;
 
   essentials_amd::graph_type view() const {
     using namespace gunrock;
-    return graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+    auto G = graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
         n_rows, n_cols, (int32_t)nnz, const_cast<int32_t*>(d_ap), const_cast<int32_t*>(d_aj),
         const_cast<float*>(d_ax));
+    if (in_edges) {
+      G.properties.directed = true;
+      in_edges->attach_to(G);
+    }
+    return G;
   }
   void adopt() {
     d_ap = ap.data();

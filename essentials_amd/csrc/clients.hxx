@@ -111,7 +111,8 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
 // (advance_direction_t::backward) while it is wide, push again for the tail.  Same
 // depths as the push-only search; new relative to the reference, whose advance
 // throws for the backward / optimized directions (configs.hxx:58-62).
-// Needs in-edges: an undirected (symmetric) CSR.
+// Needs in-edges: an undirected (symmetric) CSR, or a directed one with an attached transpose
+// (graph::build::transpose).
 // ---------------------------------------------------------------------------
 template <typename problem_type, load_balance_t lb>
 struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
@@ -186,8 +187,9 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
       //    starts (or resumes after push levels); afterwards each pull level hands its rejects
       //    over as the next level's candidates.
       if (!candidates_current) {
-        auto unvisited = [depth, G] __host__ __device__(vertex_t const& u) -> bool {
-          return depth[u] == std::numeric_limits<vertex_t>::max() && G.get_number_of_neighbors(u) > 0;
+        auto Gin = G.in_edges();
+        auto unvisited = [depth, Gin] __host__ __device__(vertex_t const& u) -> bool {
+          return depth[u] == std::numeric_limits<vertex_t>::max() && Gin.get_number_of_neighbors(u) > 0;
         };
         if (!have_candidates) {
           candidates[cand].sequence(vertex_t(0), n_vertices, ctx->stream());

@@ -157,6 +157,11 @@ int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_factor, uint
  * EMISSION order inside a row (an unsorted edge-list file); this utility produces the other
  * common layout of the same graph. */
 int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph_t* out);
+/* Build and attach the in-edge (transpose / csc) arrays of a DIRECTED graph so that pull advances
+ * (grx_options.direction_optimized) can walk in-neighbours; graphs without them are taken to be
+ * undirected (symmetric CSR = its own transpose).  Reference counterpart: the csc view of
+ * graph::build::from_csr (graph/detail/build.hxx:96-113), which it cannot combine with csr. */
+int grx_graph_build_in_edges(grx_context_t ctx, grx_graph_t g);
 int grx_graph_destroy(grx_graph_t g);
 int grx_graph_info(grx_graph_t g, int32_t* n_rows, int32_t* n_cols, int64_t* nnz,
                    const int32_t** d_row_offsets, const int32_t** d_col, const float** d_val);

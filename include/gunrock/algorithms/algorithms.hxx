@@ -34,6 +34,7 @@
 #include <gunrock/formats/formats.hxx>
 #include <gunrock/io/matrix_market.hxx>
 #include <gunrock/graph/graph.hxx>
+#include <gunrock/graph/transpose.hxx>
 
 namespace gunrock {
 using memory::memory_space_t;

@@ -603,7 +603,9 @@ namespace pull {
  * in-edges are walked (CSR view of an undirected graph = its transpose) and
  * op(in_neighbour, candidate, edge, weight) is called until it returns true; such
  * candidates are written, packed, to `output`.  The op is called at most once per in-edge
- * and never again for a candidate after its first true.  The reference declares this
+ * and never again for a candidate after its first true.  With an attached transpose the edge
+ * id handed to the op is the position in the TRANSPOSED arrays (transposed_t::edge_ids maps it
+ * back to the CSR edge).  The reference declares this
  * direction but throws for it (advance_direction_t::backward / optimized,
  * framework/operators/configs.hxx:58-62, advance/merge_path.hxx:41-56).
  *
@@ -625,9 +627,11 @@ void execute(graph_t& G,
   namespace k = detail::k;
   using vertex_t = typename graph_t::vertex_type;
   constexpr bool has_out = (output_type != advance_io_type_t::none);
-  error::throw_if_exception(G.is_directed(),
+  error::throw_if_exception(!G.can_pull(),
                             "pull advance needs in-edges: the graph is marked directed and has no "
-                            "csc view (set G.properties.directed = false for a symmetric CSR)");
+                            "attached transpose (graph::build::transpose(G, ctx).attach_to(G), or "
+                            "G.properties.directed = false for a symmetric CSR)");
+  auto Gin = G.in_edges();  // the graph whose out-edges are G's in-edges
   error::throw_if_exception(input_type != advance_io_type_t::vertices,
                             "pull advance takes a vertex frontier of candidates");
   const std::size_t n_in = input.get_number_of_elements();
@@ -656,17 +660,17 @@ void execute(graph_t& G,
   const unsigned long_grid = (unsigned)context.compute_units() * 4u;
   if (rejected) {
     k::pull_probe_kernel<output_type, true><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
-        G, op, input.data(), n_in, out_ptr, capacity, rejected->data(), long_queue,
+        Gin, op, input.data(), n_in, out_ptr, capacity, rejected->data(), long_queue,
         (unsigned long long)n_in, counters);
     k::pull_long_kernel<output_type, true><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
-        G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, rejected->data(),
+        Gin, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, rejected->data(),
         (unsigned long long)n_in, counters);
   } else {
     k::pull_probe_kernel<output_type, false><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
-        G, op, input.data(), n_in, out_ptr, capacity, (vertex_t*)nullptr, long_queue,
+        Gin, op, input.data(), n_in, out_ptr, capacity, (vertex_t*)nullptr, long_queue,
         (unsigned long long)n_in, counters);
     k::pull_long_kernel<output_type, false><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
-        G, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, (vertex_t*)nullptr, 0ull,
+        Gin, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, (vertex_t*)nullptr, 0ull,
         counters);
   }
   GRX_HIP_CHECK(hipGetLastError());

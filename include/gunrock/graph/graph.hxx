@@ -170,7 +170,27 @@ class graph_t : public graph_csr_t<vertex_t, edge_t, weight_t> {
 
   bool is_directed() const { return properties.directed; }
 
+  // --- in-edges (the csc view of reference graph/csc.hxx, as a second CSR) -------------------
+  /// Attach caller-owned arrays of the TRANSPOSE (in_offsets[V+1], in_indices[E] = sources,
+  /// in_values[E]); see graph::build::transpose.  Pull advances use them.
+  void attach_in_edges(edge_t* in_offsets, vertex_t* in_indices, weight_t* in_values) {
+    in_view_.set(this->get_number_of_vertices(), this->get_number_of_edges(), in_offsets, in_indices,
+                 in_values);
+    has_in_view_ = true;
+  }
+  bool has_in_edges() const { return has_in_view_; }
+  /// The graph whose out-edges are this graph's in-edges.  Without attached in-edges an
+  /// undirected (symmetric) graph is its own transpose; a directed one has none.
+  graph_csr_view_t in_edges() const {
+    return has_in_view_ ? in_view_ : static_cast<graph_csr_view_t const&>(*this);
+  }
+  bool can_pull() const { return has_in_view_ || !properties.directed; }
+
   graph_properties_t properties;
+
+ private:
+  graph_csr_view_t in_view_;
+  bool has_in_view_ = false;
 };
 
 namespace build {

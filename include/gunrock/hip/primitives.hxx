@@ -117,6 +117,25 @@ __device__ __forceinline__ int rightmost_le(const K* keys, key_t key, int n) {
 // device-wide (rocPRIM), temporary storage supplied by the caller
 // ---------------------------------------------------------------------------
 
+namespace detail {
+template <typename T>
+__global__ void __launch_bounds__(256) iota_kernel(T* p, std::size_t n) {
+  for (std::size_t i = blockIdx.x * (std::size_t)256 + threadIdx.x; i < n;
+       i += (std::size_t)gridDim.x * 256)
+    p[i] = (T)i;
+}
+}  // namespace detail
+
+/// p[i] = i
+template <typename T>
+void for_each_index_on(std::size_t n, T* p, hipStream_t stream) {
+  if (!n)
+    return;
+  std::size_t g = (n + 255) / 256;
+  detail::iota_kernel<<<(unsigned)(g > 4096 ? 4096 : g), 256, 0, stream>>>(p, n);
+  GRX_HIP_CHECK(hipGetLastError());
+}
+
 enum class sort_order_t { ascending, descending };
 
 template <typename key_t>

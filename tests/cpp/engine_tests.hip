@@ -264,6 +264,32 @@ int main() {
     CHECK(bm.count(ctx) == 0);
   }
 
+  // ---- transpose (in-edge view) of a directed graph ------------------------------------------
+  {
+    auto T = graph::build::transpose(G, ctx);
+    auto to = T.offsets.to_host();
+    auto ti = T.indices.to_host();
+    auto tv = T.values.to_host();
+    auto te = T.edge_ids.to_host();
+    std::vector<std::vector<std::pair<int, float>>> in(hg.n);
+    for (int v = 0; v < hg.n; ++v)
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) in[hg.aj[e]].push_back({v, hg.ax[e]});
+    bool ok = to[0] == 0 && to[hg.n] == (int)hg.aj.size();
+    for (int u = 0; u < hg.n && ok; ++u) {
+      ok &= to[u + 1] - to[u] == (int)in[u].size();
+      for (int k = 0; k < (int)in[u].size() && ok; ++k) {
+        const int e = to[u] + k;                      // stable: ascending source order
+        ok &= ti[e] == in[u][k].first && tv[e] == in[u][k].second && hg.aj[te[e]] == u;
+      }
+    }
+    CHECK(ok);
+    auto Gd = G;
+    Gd.properties.directed = true;
+    CHECK(!Gd.can_pull());
+    T.attach_to(Gd);
+    CHECK(Gd.can_pull() && Gd.has_in_edges());
+  }
+
   // ---- unsupported variants throw (reference advance.hxx:121-127) ---------------------------
   {
     frontier_t a, b;

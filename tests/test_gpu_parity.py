@@ -409,10 +409,10 @@ def test_independent_contexts_do_not_interfere(ea, torch, oracle):
 def test_direction_optimized_bfs_matches_oracle(ea, ctx, oracle, golden, lb):
     opts = ea.Options(load_balance=ea.LoadBalance[lb], direction_optimized=True)
     for name, g in golden.items():
-        if name == "rmat10_directed" or name == "sample4x4":
-            continue                      # pull needs a symmetric CSR
         Ap, Aj, Ax = golden_graph(oracle, g)
         G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        if name in ("rmat10_directed", "sample4x4"):
+            G.build_in_edges(ctx)         # directed: pull walks the attached transpose
         for run in g["runs"]:
             d, st = ea.bfs(ctx, G, run["source"], options=opts)
             assert sha(host(d)) == run["bfs_sha256"], (name, run["source"])
@@ -421,6 +421,14 @@ def test_direction_optimized_bfs_matches_oracle(ea, ctx, oracle, golden, lb):
     n, Ap, Aj, Ax = oracle.rmat_csr(16, 16, 1, 0)
     G = ea.Graph.from_host_csr(Ap, Aj, Ax)
     want, _ = oracle.bfs_heap(Ap, np.ascontiguousarray(Aj), 5)
+    # a directed graph, pulling forced: in-edges come from graph::build::transpose
+    nd, Apd, Ajd, Axd = oracle.rmat_csr(13, 8, 5, 0, False)
+    Gd = ea.Graph.from_host_csr(Apd, Ajd, Axd).build_in_edges(ctx)
+    for s in (0, 1, 77):
+        wantd, _ = oracle.bfs_heap(Apd, np.ascontiguousarray(Ajd), s)
+        d, st = ea.bfs(ctx, Gd, s, options=ea.Options(load_balance=ea.LoadBalance[lb],
+                                                      direction_optimized=True, do_alpha=1e9, do_beta=1e9))
+        assert (host(d) == wantd).all(), ("directed", s)
     for alpha, beta in ((1e9, 1e9), (1e-9, 24.0), (14.0, 24.0), (2.0, 2.0)):
         d, st = ea.bfs(ctx, G, 5, options=ea.Options(load_balance=ea.LoadBalance[lb],
                                                       direction_optimized=True, do_alpha=alpha, do_beta=beta))
