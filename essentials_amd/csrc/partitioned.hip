@@ -35,7 +35,9 @@ template <typename label_t, bool DEDUPE>
 __global__ void __launch_bounds__(256)
     pack_pairs_kernel(const int32_t* found, int64_t count, const label_t* labels, int32_t* sent,
                       int32_t round, int64_t* send, int64_t send_capacity,
-                      unsigned long long* counters) {
+                      unsigned long long* counters, const unsigned long long* count_device = nullptr) {
+  if (count_device)
+    count = (int64_t)__hip_atomic_load(count_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t rounds = (count + stride - 1) / stride;
   const int lane = hip::lane_id();
@@ -78,7 +80,8 @@ template <typename label_t, bool DEDUPE>
 __global__ void __launch_bounds__(256)
     admit_kernel(label_t* labels, int32_t* stamp, int32_t round, const int64_t* recv, int32_t world,
                  int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* next,
-                 unsigned long long next_capacity, unsigned long long* counters) {
+                 unsigned long long next_capacity, unsigned long long* next_count,
+                 unsigned long long* overflow) {
   // grid-stride over (rank, entry); ranks' slots are padded to `slot` words.  The trip count
   // is wave-uniform so that admitted vertices can be ranked with one ballot per wavefront.
   const int64_t per_rank = slot - 1;
@@ -116,14 +119,14 @@ __global__ void __launch_bounds__(256)
     if (m) {
       unsigned long long base = 0;
       if (lane == 0)
-        base = atomicAdd(&counters[hip::kernels::C_OUT], (unsigned long long)__popcll(m));
+        base = atomicAdd(next_count, (unsigned long long)__popcll(m));
       base = __shfl(base, 0, hip::wave_size);
       if (admit) {
         const unsigned long long at = base + hip::rank_in_mask(m);
         if (at < next_capacity)
           next[at] = v;
         else
-          counters[hip::kernels::C_OVERFLOW] = 1ull;
+          *overflow = 1ull;
       }
     }
   }
@@ -289,11 +292,13 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
     if (edge_op == GRX_OP_BFS)
       admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
           (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
-          (unsigned long long)next_capacity, counters);
+          (unsigned long long)next_capacity, counters + hip::kernels::C_OUT,
+          counters + hip::kernels::C_OVERFLOW);
     else
       admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
           (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
-          (unsigned long long)next_capacity, counters);
+          (unsigned long long)next_capacity, counters + hip::kernels::C_OUT,
+          counters + hip::kernels::C_OVERFLOW);
     GRX_HIP_CHECK(hipGetLastError());
     unsigned long long* m = operators::advance::detail::fetch_counters(sc);
     error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
@@ -310,6 +315,101 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
         t += h;
       *n_total_found = t;
     }
+    return (int)GRX_OK;
+  });
+}
+
+/* One fused superstep, ENQUEUE ONLY (no host wait): [admit the previous gather ->] advance over the
+ * owned frontier (length read on the device) -> pack the finds into the send slot.  The host then
+ * issues the collective on the same stream and synchronises once, on the gathered counts. */
+int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
+                         int32_t edge_op, void* d_labels, int32_t* d_stamp, int32_t* d_sent,
+                         int32_t round, const int64_t* d_recv, int32_t world, int64_t slot,
+                         int32_t me, int32_t lo, int32_t hi, int32_t* d_frontier,
+                         int64_t frontier_capacity, uint64_t* d_frontier_count, int32_t* d_scratch,
+                         int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity) {
+  if (!ctx || !local || !d_labels || !d_stamp || !d_sent || !d_frontier || !d_frontier_count ||
+      !d_scratch || !d_send || send_capacity < 2 || frontier_capacity < 1 || scratch_capacity < 1 ||
+      world < 1 || me < 0 || me >= world || (d_recv && slot < 2))
+    return invalid("grx_partitioned_step: bad arguments");
+  if (edge_op != GRX_OP_BFS && edge_op != GRX_OP_SSSP)
+    return unsupported("grx_partitioned_step: edge_op must be GRX_OP_BFS or GRX_OP_SSSP");
+  grx_options o;
+  grx_default_options(&o);
+  if (opt)
+    o = *opt;
+  return guarded([&] {
+    auto& sc = ctx->single();
+    auto& ws = sc.workspace();
+    scoped_options scope(sc, &o);
+    sc.options().holes_layout = false;
+    unsigned long long* counters = ws.counters();
+    unsigned long long* count_dev = reinterpret_cast<unsigned long long*>(d_frontier_count);
+    // the previous step's hand-off has long landed (the host synchronised on the gather since):
+    // check that nothing overflowed
+    if (ctx->pending_sequence) {
+      unsigned long long* m = operators::advance::detail::await_counters(sc, ctx->pending_sequence);
+      ctx->pending_sequence = 0;
+      error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
+                                "grx_partitioned_step: a buffer of the previous superstep overflowed");
+    }
+    // 1. admit what the other ranks found last superstep -> this superstep's owned frontier
+    if (d_recv) {
+      GRX_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), sc.stream()));
+      const int64_t total = (int64_t)world * (slot - 1);
+      const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
+                                                        (int64_t)sc.compute_units() * 8);
+      if (edge_op == GRX_OP_BFS)
+        admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
+            (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_frontier,
+            (unsigned long long)frontier_capacity, count_dev, counters + hip::kernels::C_OVERFLOW);
+      else
+        admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
+            (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_frontier,
+            (unsigned long long)frontier_capacity, count_dev, counters + hip::kernels::C_OVERFLOW);
+      GRX_HIP_CHECK(hipGetLastError());
+    }
+    // 2. local advance over the owned frontier (duplicate-free: work bounded by the rank's edges)
+    graph_type G = local->view();
+    const std::size_t bound = (std::size_t)std::min<int64_t>(frontier_capacity,
+                                                              std::max<int32_t>(hi - lo, 1));
+    if (edge_op == GRX_OP_BFS) {
+      int* depth = reinterpret_cast<int*>(d_labels);
+      const int next_level = round + 1;
+      auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                           edge_t const& e, weight_t const& w) -> bool {
+        return next_level < math::atomic::min(&depth[dst], next_level);
+      };
+      operators::advance::block_mapped::enqueue_packed(G, visit, d_frontier, bound, count_dev,
+                                                       (unsigned long long)local->nnz, d_scratch,
+                                                       (std::size_t)scratch_capacity, sc);
+    } else {
+      float* dist = reinterpret_cast<float*>(d_labels);
+      auto relax = [dist] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                              edge_t const& e, weight_t const& w) -> bool {
+        float through = thread::load(&dist[src]) + w;
+        return through < math::atomic::min(&dist[dst], through);
+      };
+      operators::advance::block_mapped::enqueue_packed(G, relax, d_frontier, bound, count_dev,
+                                                       (unsigned long long)local->nnz, d_scratch,
+                                                       (std::size_t)scratch_capacity, sc);
+    }
+    // 3. pack the finds (their number is counters[C_OUT], still on the device)
+    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
+                                 sc.stream()));
+    const unsigned pgrid = (unsigned)sc.compute_units() * 8;
+    if (edge_op == GRX_OP_BFS)
+      pack_pairs_kernel<int32_t, false><<<pgrid, 256, 0, sc.stream()>>>(
+          d_scratch, 0, (int32_t*)d_labels, d_sent, round, d_send, send_capacity, counters,
+          counters + hip::kernels::C_OUT);
+    else
+      pack_pairs_kernel<float, true><<<pgrid, 256, 0, sc.stream()>>>(
+          d_scratch, 0, (float*)d_labels, d_sent, round, d_send, send_capacity, counters,
+          counters + hip::kernels::C_OUT);
+    publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
+    GRX_HIP_CHECK(hipGetLastError());
+    // 4. hand the counters over (overflow flag) and clear them -- nobody waits here
+    ctx->pending_sequence = operators::advance::detail::publish_counters(sc);
     return (int)GRX_OK;
   });
 }

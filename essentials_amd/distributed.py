@@ -160,15 +160,33 @@ class HipKernels:
         return n_next.value
 
 
+    def step(self, op, labels, stamp, sent, rnd, recv, world, slot, rank, lo, hi, frontier, fcount,
+             scratch, send) -> None:
+        """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> advance -> pack."""
+        ea._check(self.lib.grx_partitioned_step(
+            self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), stamp.data_ptr(),
+            sent.data_ptr(), rnd, recv.data_ptr() if recv is not None else None, world, slot, rank,
+            lo, hi, frontier.data_ptr(), frontier.numel(), fcount.data_ptr(), scratch.data_ptr(),
+            scratch.numel(), send.data_ptr(), send.numel()), "grx_partitioned_step")
+
+
 class PartitionedTraversal:
     """BSP supersteps of a vertex-partitioned BFS / SSSP over `dist` (torch.distributed or None)."""
 
     SMALL_SLOT = 1 << 15  # int64 words per rank in the first all-gather (256 KiB)
 
     def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int,
-                 local_nnz: int, device, small_slot: int | None = None):
+                 local_nnz: int, device, small_slot: int | None = None, fused: bool = True,
+                 stream=None):
+        """fused=True uses kernels.step (one enqueue-only call + one host synchronisation per
+        superstep); it needs the engine context and the collectives on ONE stream: pass that
+        torch stream as `stream` (the context must have been created on stream.cuda_stream)."""
         import torch
         self.torch = torch
+        # without a shared stream the fused loop would race on device tensors: use the two-call loop
+        on_device = str(device).startswith("cuda")
+        self.fused = fused and hasattr(kernels, "step") and (stream is not None or not on_device)
+        self.stream = stream
         self.k, self.dist = kernels, dist
         self.rank, self.world, self.n, self.lo, self.hi = rank, world, n_global, lo, hi
         self.device = device
@@ -181,6 +199,7 @@ class PartitionedTraversal:
         self.frontier = [torch.empty(own + 64, dtype=i32, device=device) for _ in range(2)]
         self.scratch = torch.empty(max(local_nnz, 1) + n_global + 64, dtype=i32, device=device)
         self.send = torch.zeros(n_global + 2, dtype=i64, device=device)
+        self.fcount = torch.zeros(1, dtype=i64, device=device)
         self.recv = torch.zeros(world * self.slot0, dtype=i64, device=device)
         self._recv_big = None
         self._backend = dist.get_backend() if dist is not None and world > 1 else None
@@ -201,6 +220,57 @@ class PartitionedTraversal:
 
     def run(self, op: int, source: int, labels) -> dict:
         """labels: replica [V] (int32 for BFS, float32 for SSSP), overwritten."""
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                return self._run_fused(op, source, labels) if self.fused else self._run(op, source, labels)
+        return self._run_fused(op, source, labels) if self.fused else self._run(op, source, labels)
+
+    def _run_fused(self, op: int, source: int, labels) -> dict:
+        torch = self.torch
+        unreached = ea.INT_UNREACHED if op == OP_BFS else ea.FLT_UNREACHED
+        labels.fill_(unreached)
+        labels[source] = 0
+        self.stamp.fill_(-1)
+        self.sent.fill_(-1)
+        frontier = self.frontier[0]
+        owned = self.lo <= source < self.hi
+        if owned:
+            frontier[0] = source
+        self.fcount.fill_(1 if owned else 0)
+        if labels.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        t0 = time.perf_counter()
+        rounds = found_total = collectives = 0
+        recv_prev, slot_prev = None, 0
+        while True:
+            self.k.step(op, labels, self.stamp, self.sent, rounds, recv_prev, self.world, slot_prev,
+                        self.rank, self.lo, self.hi, frontier, self.fcount, self.scratch, self.send)
+            slot = self.slot0
+            recv = self.recv
+            self._all_gather(recv, self.send[:slot])
+            collectives += 1
+            heads = recv.view(self.world, slot)[:, 0]
+            counts = heads.cpu() if heads.is_cuda else heads.clone()   # the one host wait
+            most = int(counts.max())
+            if most == 0:
+                break
+            if most > slot - 1:
+                slot = min(((most + 1 + 4095) // 4096) * 4096, self.send.numel())
+                if self._recv_big is None or self._recv_big.numel() < self.world * slot:
+                    self._recv_big = torch.zeros(self.world * slot, dtype=torch.int64,
+                                                 device=self.device)
+                recv = self._recv_big[: self.world * slot]
+                self._all_gather(recv, self.send[:slot])   # same stream: ordered before the admit
+                collectives += 1
+            found_total += int(counts.sum())
+            recv_prev, slot_prev = recv, slot
+            rounds += 1
+        if labels.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
+                "pairs_exchanged": found_total, "collectives": collectives, "fused": True}
+
+    def _run(self, op: int, source: int, labels) -> dict:
         torch = self.torch
         unreached = ea.INT_UNREACHED if op == OP_BFS else ea.FLT_UNREACHED
         labels.fill_(unreached)
@@ -271,8 +341,12 @@ class PartitionedRunner:
     def __init__(self, ctx: ea.Context, dist, scale, edge_factor, seed, weight_seed,
                  options: ea.Options | None = None):
         import torch
-        self.ctx, self.dist = ctx, dist
+        self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        # ONE stream for the engine's kernels, torch's tensor ops and the collectives: the fused
+        # superstep needs no cross-stream waits
+        self.stream = torch.cuda.Stream(device=ctx.device)
+        self.ctx = ctx = ea.Context(ctx.device, stream=self.stream.cuda_stream)
         full = ea.Graph.rmat(ctx, scale, edge_factor, seed, weight_seed, True)
         self.n, self.nnz = full.n_rows, full.nnz
         self._host = full.to_host() if self.rank == 0 else None
@@ -290,8 +364,11 @@ class PartitionedRunner:
         dev = f"cuda:{ctx.device}"
         self.depth = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.distance = torch.empty(self.n, dtype=torch.float32, device=dev)
-        self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist, self.rank,
-                                         self.world, self.n, self.lo, self.hi, self.local.nnz, dev)
+        fused = options is None or options.load_balance == ea.LoadBalance.block_mapped
+        with torch.cuda.stream(self.stream):
+            self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist, self.rank,
+                                             self.world, self.n, self.lo, self.hi, self.local.nnz,
+                                             dev, fused=fused, stream=self.stream)
         self._deg_dev = torch.from_numpy(self._deg).to(dev)
         self.last = {}
 

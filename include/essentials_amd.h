@@ -241,6 +241,19 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
                           int32_t my_rank, int32_t row_begin, int32_t row_end, int32_t* d_next,
                           int64_t next_capacity, int64_t* n_next, int64_t* n_total_found);
 
+/* The same superstep FUSED and enqueue-only (block_mapped schedule): [admit d_recv, the previous
+ * gather, into d_frontier / *d_frontier_count ->] advance over d_frontier (its length is read on
+ * the DEVICE from *d_frontier_count) -> pack into d_send.  Nothing is awaited: the caller issues
+ * the collective on the SAME stream (create the context on that stream) and synchronises once per
+ * superstep, on the gathered counts.  d_recv == NULL on the first superstep (the caller preset
+ * d_frontier / *d_frontier_count).  Buffer overflows of a step are reported by the next call. */
+int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
+                         int32_t edge_op, void* d_labels, int32_t* d_stamp, int32_t* d_sent_stamp,
+                         int32_t round, const int64_t* d_recv, int32_t world_size, int64_t slot,
+                         int32_t my_rank, int32_t row_begin, int32_t row_end, int32_t* d_frontier,
+                         int64_t frontier_capacity, uint64_t* d_frontier_count, int32_t* d_scratch,
+                         int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity);
+
 /* ---- measurement helpers ------------------------------------------------- */
 /* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:
  * the achievable-HBM roof quoted beside the 8 TB/s vendor peak. Returns GB/s. */

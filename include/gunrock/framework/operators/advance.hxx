@@ -77,15 +77,21 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
   }
 }
 
-/// Publish the counters and wait for them; returns the pinned mirror.
-inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
+/// Enqueue the hand-off (copy to the mirror, clear, stamp); returns the sequence number.
+inline unsigned long long publish_counters(gcuda::standard_context_t& ctx) {
   auto& ws = ctx.workspace();
   const unsigned long long seq = ws.next_sequence();
   publish_counters_kernel<0><<<1, 64, 0, ctx.stream()>>>(ws.counters(), ws.mirror(), seq);
   GRX_HIP_CHECK(hipGetLastError());
+  return seq;
+}
+
+/// Wait until hand-off `seq` has landed; returns the pinned mirror.
+inline unsigned long long* await_counters(gcuda::standard_context_t& ctx, unsigned long long seq) {
+  auto& ws = ctx.workspace();
   volatile unsigned long long* flag = ws.mirror() + gcuda::workspace_t::sequence_slot;
   unsigned spins = 0;
-  while (*flag != seq) {
+  while (*flag < seq) {
     __builtin_ia32_pause();
     if ((++spins & 0xFFFFu) == 0) {
       // every ~100 us: make sure the stream is still healthy (a faulted kernel never publishes)
@@ -96,6 +102,11 @@ inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return ws.mirror();
+}
+
+/// Publish the counters and wait for them; returns the pinned mirror.
+inline unsigned long long* fetch_counters(gcuda::standard_context_t& ctx) {
+  return await_counters(ctx, publish_counters(ctx));
 }
 
 struct clocked_t {
@@ -299,6 +310,45 @@ void execute(graph_t& G,
     detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
+}
+
+/**
+ * @brief Enqueue-only form for fused pipelines (vertex-partitioned supersteps): packed output,
+ * frontier length read from DEVICE memory (`n_in_device`, at most `n_in_bound`), nothing fetched,
+ * nothing awaited.  The caller reads counters[C_OUT] / the counters' hand-off later.
+ */
+template <typename graph_t, typename operator_t, typename vertex_t>
+void enqueue_packed(graph_t& G,
+                    operator_t op,
+                    const vertex_t* input,
+                    std::size_t n_in_bound,
+                    const unsigned long long* n_in_device,
+                    unsigned long long work_bound,
+                    vertex_t* output,
+                    std::size_t capacity,
+                    gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using edge_t = typename graph_t::edge_type;
+  constexpr advance_io_type_t vin = advance_io_type_t::vertices;
+  if (n_in_bound == 0)
+    return;
+  const unsigned long long max_deg = detail::max_degree(G, context);
+  unsigned long long chunk_capacity = 0;
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, n_in_bound, work_bound, chunk_capacity, context);
+  const unsigned hub_threshold = context.options().hub_threshold;
+  const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
+  unsigned long long* counters = context.workspace().counters();
+  const std::size_t n_tiles = (n_in_bound + k::ADV_BLOCK - 1) / k::ADV_BLOCK;
+  const unsigned persistent = (unsigned)context.compute_units() * context.options().tile_blocks_per_cu;
+  const unsigned grid = (unsigned)(n_tiles < persistent ? n_tiles : persistent);
+  k::block_mapped_kernel<false, false, vin, vin><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
+      G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, hub_threshold,
+      chunk_edges, n_in_device);
+  if (max_deg >= hub_threshold)
+    k::chunk_kernel<vin><<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu,
+                           k::ADV_BLOCK, 0, context.stream()>>>(G, op, chunks, chunk_capacity, output,
+                                                                capacity, counters);
+  GRX_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace block_mapped

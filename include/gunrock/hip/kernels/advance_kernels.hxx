@@ -237,10 +237,15 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                         chunk_t<vertex_t, edge_t>* chunks,
                         unsigned long long chunk_capacity,
                         unsigned hub_threshold,
-                        unsigned chunk_edges) {
+                        unsigned chunk_edges,
+                        const unsigned long long* n_in_device = nullptr) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   constexpr bool PACKED = HAS_OUT && !HOLES;
+  // the frontier length may live on the device (a producer kernel earlier in the stream wrote
+  // it): no host round trip between producing and consuming a frontier
+  if (n_in_device)
+    n_in = (std::size_t)__hip_atomic_load(n_in_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   __shared__ vertex_t s_vertex[ADV_BLOCK];
   __shared__ edge_t s_first[ADV_BLOCK];

@@ -56,6 +56,13 @@ class NumpyKernels:
             s[1:1 + k] = (bits << 32) | f
         return len(found)
 
+    def step(self, op, labels, stamp, sent, rnd, recv, world, slot, rank, lo, hi, frontier, fcount,
+             scratch, send):
+        """grx_partitioned_step: admit the previous gather, advance, pack -- no result returned."""
+        if recv is not None:
+            fcount[0] = self.admit(op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, frontier)
+        self.expand(op, labels, rnd, frontier, int(fcount[0]), scratch, sent, send)
+
     def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
         lab, st, r, out = labels.numpy(), stamp.numpy(), recv.numpy().reshape(world, slot), nxt.numpy()
         n = 0
@@ -79,7 +86,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir):
+def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -90,7 +97,7 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir)
     lo, hi = b[rank], b[rank + 1]
     k = NumpyKernels(Ap, np.ascontiguousarray(Aj), np.ascontiguousarray(Ax), lo, hi)
     trav = PartitionedTraversal(k, dist, rank, world, n, lo, hi, int(Ap[hi] - Ap[lo]), "cpu",
-                                small_slot=small_slot)
+                                small_slot=small_slot, fused=fused)
     ok = True
     why = []
     for s in sources:
@@ -112,11 +119,13 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,small_slot", [(2, None), (2, 8), (3, 64)])
-def test_partitioned_traversal_gloo(tmp_path, world, small_slot):
-    """small_slot 8 / 64 forces the second (big-slot) all-gather on the wide levels."""
+@pytest.mark.parametrize("world,small_slot,fused", [(2, None, True), (2, 8, True), (3, 64, True),
+                                                    (2, 8, False)])
+def test_partitioned_traversal_gloo(tmp_path, world, small_slot, fused):
+    """small_slot 8 / 64 forces the second (big-slot) all-gather on the wide levels; fused=True is
+    the one-call-per-superstep loop bench.py uses, False the two-call (expand / admit) loop."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path)),
+    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path), fused),
              nprocs=world, join=True)
     names = sorted(os.listdir(tmp_path))
     notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}

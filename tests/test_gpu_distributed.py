@@ -53,12 +53,14 @@ def test_partitioned_world1_matches_oracle(oracle):
     import torch
     import essentials_amd as ea
     from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
-    ctx = ea.Context(0)
+    stream = torch.cuda.Stream()
+    ctx = ea.Context(0, stream=stream.cuda_stream)      # the fused loop needs ONE stream
     g = ea.Graph.rmat(ctx, 14, 16, 1, 7)
     Ap, Aj, Ax = g.to_host()
-    for small_slot in (None, 16):
+    for small_slot, fused in ((None, True), (16, True), (16, False)):
         trav = PartitionedTraversal(HipKernels(ctx, g), None, 0, 1, g.n_rows, 0, g.n_rows, g.nnz,
-                                    "cuda:0", small_slot=small_slot)
+                                    "cuda:0", small_slot=small_slot, fused=fused, stream=stream)
+        assert trav.fused == fused
         for s in (0, 7217):
             depth = torch.empty(g.n_rows, dtype=torch.int32, device="cuda")
             st = trav.run(OP_BFS, s, depth)
@@ -83,7 +85,8 @@ def _rank(rank, world, port, scale, out_dir):
     from oracle.oracle import Oracle
     o = Oracle()
     torch.cuda.set_device(0)
-    ctx = ea.Context(0)
+    stream = torch.cuda.Stream()
+    ctx = ea.Context(0, stream=stream.cuda_stream)      # engine + collectives on one stream
     full = ea.Graph.rmat(ctx, scale, 16, 1, 7)
     Ap, Aj, Ax = full.to_host()
     h, lo, hi = api._VP(), C.c_int32(), C.c_int32()
@@ -93,9 +96,11 @@ def _rank(rank, world, port, scale, out_dir):
     notes = []
     for lb, small_slot in ((ea.LoadBalance.block_mapped, None), (ea.LoadBalance.block_mapped, 64),
                            (ea.LoadBalance.merge_path, None), (ea.LoadBalance.merge_path, 64)):
+        # block_mapped: the fused one-call superstep; merge_path: the two-call loop
         trav = PartitionedTraversal(HipKernels(ctx, local, ea.Options(load_balance=lb)), dist, rank,
                                     world, full.n_rows, lo.value, hi.value, local.nnz, "cuda:0",
-                                    small_slot=small_slot)
+                                    small_slot=small_slot, fused=(lb == ea.LoadBalance.block_mapped),
+                                    stream=stream)
         for s in (0, 1830):
             depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
             trav.run(OP_BFS, s, depth)
