@@ -294,20 +294,20 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
     int* stamp = P->stamp.data();
     const int round = this->iteration;
 
-    auto relax = [distance] __host__ __device__(vertex_t const& src, vertex_t const& dst,
-                                                edge_t const& edge, weight_t const& w) -> bool {
+    // Relax and keep ONE copy of an improved vertex per round: the exchange on its stamp admits
+    // exactly the first improver, so the output frontier is duplicate-free and the reference's
+    // separate filter pass (sssp.hxx:126-139, a racy stamp test that lets concurrent duplicates
+    // through) is not needed.  Later improvements of the same round still lower distance[dst];
+    // the next round reads the latest value.
+    auto relax = [distance, stamp, round] __host__ __device__(
+                     vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                     weight_t const& w) -> bool {
       weight_t through = thread::load(&distance[src]) + w;
-      return through < math::atomic::min(&distance[dst], through);
-    };
-    // keep one copy of a vertex per round (benign race: a duplicate may survive)
-    auto once_per_round = [stamp, round] __host__ __device__(vertex_t const& v) -> bool {
-      if (stamp[v] == round)
+      if (!(through < math::atomic::min(&distance[dst], through)))
         return false;
-      stamp[v] = round;
-      return true;
+      return math::atomic::exch(&stamp[dst], round) != round;
     };
     operators::advance::execute<lb>(G, E, relax, context);
-    operators::filter::execute<operators::filter_algorithm_t::bypass>(G, E, once_per_round, context);
   }
 };
 

@@ -28,47 +28,78 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-/// Pack the finds of one superstep, ONE pair per vertex (a vertex improved several times
-/// appears several times in the raw output): send[1 + k] = (vertex | label bits << 32), the
-/// label read after the advance, i.e. the best this rank knows.  counters[C_SELECT] counts them.
-template <typename label_t, bool DEDUPE>
+constexpr int APPEND_ITEMS = 8;                   // items per thread and round
+constexpr int APPEND_TILE = 256 * APPEND_ITEMS;   // items per workgroup and round
+
+/// LDS of one workgroup-wide append: the kept items of a tile are ranked with a workgroup scan,
+/// staged, and written with ONE cursor atomic per tile (a single-address atomic retires at
+/// ~90/us on this part -- one per wavefront made these kernels cursor-bound).
+template <typename T>
+struct tile_append_t {
+  T staged[APPEND_TILE];
+  unsigned wave_totals[256 / hip::wave_size + 1];
+  unsigned long long base;
+};
+
+/// Every thread of the workgroup calls this with its (up to APPEND_ITEMS) kept values.
+template <typename T>
+__device__ __forceinline__ void append_tile(tile_append_t<T>& s, const T (&val)[APPEND_ITEMS],
+                                            unsigned keep, T* out, unsigned long long capacity,
+                                            unsigned long long* cursor, unsigned long long* overflow) {
+  unsigned total = 0;
+  unsigned at = hip::block_exclusive_sum<256>((unsigned)__popc(keep), total, s.wave_totals);
+  if (total == 0)  // workgroup-uniform
+    return;
+#pragma unroll
+  for (int k = 0; k < APPEND_ITEMS; ++k)
+    if (keep & (1u << k))
+      s.staged[at++] = val[k];
+  if (threadIdx.x == 0)
+    s.base = atomicAdd(cursor, (unsigned long long)total);
+  __syncthreads();
+  const unsigned long long base = s.base;
+  for (unsigned i = threadIdx.x; i < total; i += 256) {
+    if (base + i < capacity)
+      out[base + i] = s.staged[i];
+    else
+      *overflow = 1ull;
+  }
+  __syncthreads();  // staged[] is reused by the next tile
+}
+
+/// Pack the finds of one superstep (duplicate-free: a BFS level discovers a vertex once per rank,
+/// the SSSP relax lambda keeps the first improver per superstep): send[1 + k] = (vertex | label
+/// bits << 32), the label read AFTER the advance, i.e. the best this rank knows.
+/// counters[C_SELECT] counts them.
+template <typename label_t>
 __global__ void __launch_bounds__(256)
-    pack_pairs_kernel(const int32_t* found, int64_t count, const label_t* labels, int32_t* sent,
-                      int32_t round, int64_t* send, int64_t send_capacity,
+    pack_pairs_kernel(const int32_t* found, int64_t count, const label_t* labels, int64_t* send,
+                      int64_t send_capacity,
                       unsigned long long* counters, const unsigned long long* count_device = nullptr) {
+  __shared__ tile_append_t<int64_t> lds;
   if (count_device)
     count = (int64_t)__hip_atomic_load(count_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t stride = (int64_t)gridDim.x * APPEND_TILE;
   const int64_t rounds = (count + stride - 1) / stride;
-  const int lane = hip::lane_id();
   for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t i = r * stride + blockIdx.x * 256ll + threadIdx.x;
-    bool first = false;
-    int32_t v = -1;
-    if (i < count) {
-      v = found[i];
-      // SSSP may improve a vertex several times in one superstep: exactly one packer per vertex
-      // and round.  A BFS level discovers a vertex once per rank (atomic::min), no test needed.
-      first = DEDUPE ? (atomicExch(&sent[v], round) != round) : true;
-    }
-    const unsigned long long m = __ballot(first);
-    if (m) {
-      unsigned long long base = 0;
-      if (lane == 0)
-        base = atomicAdd(&counters[hip::kernels::C_SELECT], (unsigned long long)__popcll(m));
-      base = __shfl(base, 0, hip::wave_size);
-      if (first) {
-        const long long at = (long long)(base + hip::rank_in_mask(m));
-        if (at < send_capacity - 1) {
-          const label_t l = labels[v];
-          uint32_t bits;
-          __builtin_memcpy(&bits, &l, 4);
-          send[1 + at] = (int64_t)(((uint64_t)bits << 32) | (uint32_t)v);
-        } else {
-          counters[hip::kernels::C_OVERFLOW] = 1ull;
-        }
+    const int64_t tile = r * stride + (int64_t)blockIdx.x * APPEND_TILE;
+    int64_t pair[APPEND_ITEMS];
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < APPEND_ITEMS; ++k) {
+      const int64_t i = tile + k * 256 + threadIdx.x;
+      pair[k] = 0;
+      if (i < count) {
+        const int32_t v = found[i];
+        const label_t l = labels[v];
+        uint32_t bits;
+        __builtin_memcpy(&bits, &l, 4);
+        pair[k] = (int64_t)(((uint64_t)bits << 32) | (uint32_t)v);
+        keep |= 1u << k;
       }
     }
+    append_tile(lds, pair, keep, send + 1, (unsigned long long)(send_capacity - 1),
+                counters + hip::kernels::C_SELECT, counters + hip::kernels::C_OVERFLOW);
   }
 }
 
@@ -82,53 +113,47 @@ __global__ void __launch_bounds__(256)
                  int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* next,
                  unsigned long long next_capacity, unsigned long long* next_count,
                  unsigned long long* overflow) {
-  // grid-stride over (rank, entry); ranks' slots are padded to `slot` words.  The trip count
-  // is wave-uniform so that admitted vertices can be ranked with one ballot per wavefront.
+  // tiles over (rank, entry); ranks' slots are padded to `slot` words.  The trip count is
+  // workgroup-uniform (append_tile synchronises).
+  __shared__ tile_append_t<int32_t> lds;
   const int64_t per_rank = slot - 1;
   const int64_t total = (int64_t)world * per_rank;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t stride = (int64_t)gridDim.x * APPEND_TILE;
   const int64_t rounds = (total + stride - 1) / stride;
-  const int lane = hip::lane_id();
   for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t t = r * stride + blockIdx.x * 256ll + threadIdx.x;
-    bool admit = false;
-    int32_t v = -1;
-    if (t < total) {
-      const int32_t p = (int32_t)(t / per_rank);
-      const int64_t i = t - (int64_t)p * per_rank;
-      const int64_t* seg = recv + (int64_t)p * slot;
-      const int64_t cnt = seg[0] < per_rank ? seg[0] : per_rank;
-      if (i < cnt) {
-        const uint64_t word = (uint64_t)seg[1 + i];
-        v = (int32_t)(uint32_t)word;
-        const uint32_t bits = (uint32_t)(word >> 32);
-        label_t l;
-        __builtin_memcpy(&l, &bits, 4);
-        // this rank's own advance already improved its own finds
-        const bool fresh = (p == me) ? true : (l < math::atomic::min(&labels[v], l));
-        // exactly one copy per superstep (the reference's SSSP bypass predicate,
-        // sssp.hxx:126-136, tolerates duplicates; here the frontier stays duplicate-free so
-        // that its work is bounded by the rank's edge count)
-        // BFS: every rank proposes the same label, so exactly one proposal is fresh (this
-        // rank's own, or the first one to win the atomic::min) -- no stamp needed
-        if (fresh && v >= lo && v < hi && (!DEDUPE || atomicExch(&stamp[v], round) != round))
-          admit = true;
+    const int64_t tile = r * stride + (int64_t)blockIdx.x * APPEND_TILE;
+    int32_t admitted[APPEND_ITEMS];
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < APPEND_ITEMS; ++k) {
+      const int64_t t = tile + k * 256 + threadIdx.x;
+      admitted[k] = -1;
+      if (t < total) {
+        const int32_t p = (int32_t)(t / per_rank);
+        const int64_t i = t - (int64_t)p * per_rank;
+        const int64_t* seg = recv + (int64_t)p * slot;
+        const int64_t cnt = seg[0] < per_rank ? seg[0] : per_rank;
+        if (i < cnt) {
+          const uint64_t word = (uint64_t)seg[1 + i];
+          const int32_t v = (int32_t)(uint32_t)word;
+          const uint32_t bits = (uint32_t)(word >> 32);
+          label_t l;
+          __builtin_memcpy(&l, &bits, 4);
+          // this rank's own advance already improved its own finds
+          const bool fresh = (p == me) ? true : (l < math::atomic::min(&labels[v], l));
+          // exactly one copy per superstep (the reference's SSSP bypass predicate,
+          // sssp.hxx:126-136, tolerates duplicates; here the frontier stays duplicate-free so
+          // that its work is bounded by the rank's edge count)
+          // BFS: every rank proposes the same label, so exactly one proposal is fresh (this
+          // rank's own, or the first one to win the atomic::min) -- no stamp needed
+          if (fresh && v >= lo && v < hi && (!DEDUPE || atomicExch(&stamp[v], round) != round)) {
+            admitted[k] = v;
+            keep |= 1u << k;
+          }
+        }
       }
     }
-    const unsigned long long m = __ballot(admit);
-    if (m) {
-      unsigned long long base = 0;
-      if (lane == 0)
-        base = atomicAdd(next_count, (unsigned long long)__popcll(m));
-      base = __shfl(base, 0, hip::wave_size);
-      if (admit) {
-        const unsigned long long at = base + hip::rank_in_mask(m);
-        if (at < next_capacity)
-          next[at] = v;
-        else
-          *overflow = 1ull;
-      }
-    }
+    append_tile(lds, admitted, keep, next, next_capacity, next_count, overflow);
   }
 }
 
@@ -164,10 +189,17 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
                                                                *ctx->mc);
     } else {
       float* dist = reinterpret_cast<float*>(labels);
-      auto relax = [dist] __host__ __device__(vertex_t const& src, vertex_t const& dst,
-                                              edge_t const& e, weight_t const& w) -> bool {
+      // one copy of an improved vertex per superstep (the first improver wins the exchange on
+      // its `sent` stamp): the raw output is duplicate-free; later improvements still lower
+      // dist[dst] and the pack reads the latest value
+      int32_t* sent = d_sent;
+      const int32_t rnd = iparam;
+      auto relax = [dist, sent, rnd] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                         edge_t const& e, weight_t const& w) -> bool {
         float through = thread::load(&dist[src]) + w;
-        return through < math::atomic::min(&dist[dst], through);
+        if (!(through < math::atomic::min(&dist[dst], through)))
+          return false;
+        return math::atomic::exch(&sent[dst], rnd) != rnd;
       };
       operators::advance::execute<lb, advance_direction_t::forward, advance_io_type_t::vertices,
                                   advance_io_type_t::vertices>(G, relax, &fin, &fout, segments,
@@ -179,14 +211,10 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
                                  sc.stream()));
     if (count) {
-      const unsigned grid = (unsigned)std::min<int64_t>((count + 255) / 256,
+      const unsigned grid = (unsigned)std::min<int64_t>((count + APPEND_TILE - 1) / APPEND_TILE,
                                                         (int64_t)sc.compute_units() * 8);
-      if (edge_op == GRX_OP_BFS)
-        pack_pairs_kernel<label_t, false><<<grid, 256, 0, sc.stream()>>>(
-            d_scratch, count, labels, d_sent, iparam, d_send, send_capacity, counters);
-      else
-        pack_pairs_kernel<label_t, true><<<grid, 256, 0, sc.stream()>>>(
-            d_scratch, count, labels, d_sent, iparam, d_send, send_capacity, counters);
+      pack_pairs_kernel<label_t><<<grid, 256, 0, sc.stream()>>>(d_scratch, count, labels, d_send,
+                                                                 send_capacity, counters);
     }
     publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
     GRX_HIP_CHECK(hipGetLastError());
@@ -287,7 +315,7 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
     auto& ws = sc.workspace();
     unsigned long long* counters = ws.counters();  // zero between operators (see fetch_counters)
     const int64_t total = (int64_t)world * (slot - 1);
-    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
+    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + APPEND_TILE - 1) / APPEND_TILE, 1),
                                                       (int64_t)sc.compute_units() * 8);
     if (edge_op == GRX_OP_BFS)
       admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
@@ -357,7 +385,7 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
     if (d_recv) {
       GRX_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), sc.stream()));
       const int64_t total = (int64_t)world * (slot - 1);
-      const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1),
+      const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + APPEND_TILE - 1) / APPEND_TILE, 1),
                                                         (int64_t)sc.compute_units() * 8);
       if (edge_op == GRX_OP_BFS)
         admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
@@ -385,10 +413,17 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                                                        (std::size_t)scratch_capacity, sc);
     } else {
       float* dist = reinterpret_cast<float*>(d_labels);
-      auto relax = [dist] __host__ __device__(vertex_t const& src, vertex_t const& dst,
-                                              edge_t const& e, weight_t const& w) -> bool {
+      // one copy of an improved vertex per superstep (the first improver wins the exchange on
+      // its `sent` stamp): the raw output is duplicate-free; later improvements still lower
+      // dist[dst] and the pack reads the latest value
+      int32_t* sent = d_sent;
+      const int32_t rnd = round;
+      auto relax = [dist, sent, rnd] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                         edge_t const& e, weight_t const& w) -> bool {
         float through = thread::load(&dist[src]) + w;
-        return through < math::atomic::min(&dist[dst], through);
+        if (!(through < math::atomic::min(&dist[dst], through)))
+          return false;
+        return math::atomic::exch(&sent[dst], rnd) != rnd;
       };
       operators::advance::block_mapped::enqueue_packed(G, relax, d_frontier, bound, count_dev,
                                                        (unsigned long long)local->nnz, d_scratch,
@@ -399,12 +434,12 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                                  sc.stream()));
     const unsigned pgrid = (unsigned)sc.compute_units() * 8;
     if (edge_op == GRX_OP_BFS)
-      pack_pairs_kernel<int32_t, false><<<pgrid, 256, 0, sc.stream()>>>(
-          d_scratch, 0, (int32_t*)d_labels, d_sent, round, d_send, send_capacity, counters,
+      pack_pairs_kernel<int32_t><<<pgrid, 256, 0, sc.stream()>>>(
+          d_scratch, 0, (int32_t*)d_labels, d_send, send_capacity, counters,
           counters + hip::kernels::C_OUT);
     else
-      pack_pairs_kernel<float, true><<<pgrid, 256, 0, sc.stream()>>>(
-          d_scratch, 0, (float*)d_labels, d_sent, round, d_send, send_capacity, counters,
+      pack_pairs_kernel<float><<<pgrid, 256, 0, sc.stream()>>>(
+          d_scratch, 0, (float*)d_labels, d_send, send_capacity, counters,
           counters + hip::kernels::C_OUT);
     publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
     GRX_HIP_CHECK(hipGetLastError());
