@@ -179,6 +179,7 @@ _SIGNATURES = {
                                        C.c_int32, _VP, C.c_int64, _VP, _VP, C.c_int64, _VP,
                                        C.c_int64]),
     "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "grx_measure_gather_rate": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -255,6 +256,14 @@ class Context:
         _check(load_library().grx_measure_copy_bandwidth(self._h, nbytes, repeats, g),
                "grx_measure_copy_bandwidth")
         return g.value
+
+    def gather_rate(self, graph, mode: int = 1, repeats: int = 5) -> float:
+        """Random-gather ceiling of `graph` in lookups (= edges) per second: table[column[i]] over
+        all edges; mode 1 = the agent-scope loads atomic::min pre-tests with, 0 = plain loads."""
+        r = C.c_double()
+        _check(load_library().grx_measure_gather_rate(self._h, graph._h, mode, repeats, r),
+               "grx_measure_gather_rate")
+        return r.value
 
     def close(self) -> None:
         if self._h:

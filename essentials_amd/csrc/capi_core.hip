@@ -219,7 +219,58 @@ __global__ void __launch_bounds__(256) copy16_kernel(const uint4* __restrict__ i
        i += (std::size_t)gridDim.x * 256)
     out[i] = in[i];
 }
+/// acc += table[columns[i]]: the access pattern every label-testing advance functor shares, with
+/// none of the frontier logic, atomics or output (MODE 0 = plain L1-cached load, 1 = the
+/// agent-scope relaxed load math::atomic::min pre-tests with).
+__global__ void __launch_bounds__(256)
+    gather_probe_kernel(const int32_t* columns, std::size_t n, const int32_t* table,
+                        unsigned long long* sink, int MODE) {
+  unsigned long long acc = 0;
+  const std::size_t stride = (std::size_t)gridDim.x * 256;
+  for (std::size_t i = blockIdx.x * (std::size_t)256 + threadIdx.x; i < n; i += stride) {
+    const int32_t j = __builtin_nontemporal_load(columns + i);
+    acc += (unsigned)(MODE == 0 ? table[j]
+                                : __hip_atomic_load(table + j, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT));
+  }
+  if (acc == 0x5eed5eed5eed5eedull)  // never true for the all-ones table: keeps the loads alive
+    *sink = acc;
+}
 }  // namespace
+
+int grx_measure_gather_rate(grx_context_t ctx, grx_graph_t g, int mode, int repeats,
+                            double* lookups_per_second) {
+  if (!ctx || !g || !lookups_per_second || repeats < 1 || mode < 0 || mode > 1)
+    return invalid("grx_measure_gather_rate: bad arguments");
+  if (g->nnz < 1)
+    return invalid("grx_measure_gather_rate: graph has no edges");
+  return guarded([&] {
+    auto& c = ctx->single();
+    const std::size_t n = (std::size_t)g->nnz;
+    const std::size_t cols = (std::size_t)std::max(g->n_cols, g->n_rows);
+    hip::buffer_t<int32_t> table(cols);
+    hip::buffer_t<unsigned long long> sink(1);
+    GRX_HIP_CHECK(hipMemsetAsync(table.data(), 1, cols * 4, c.stream()));
+    const unsigned grid = (unsigned)c.compute_units() * 8;
+    auto launch = [&] {
+      gather_probe_kernel<<<grid, 256, 0, c.stream()>>>(g->d_aj, n, table.data(), sink.data(), mode);
+    };
+    launch();
+    c.synchronize();
+    float best = 0;
+    for (int r = 0; r < repeats; ++r) {
+      util::timer_t t(c.stream());
+      t.begin();
+      launch();
+      GRX_HIP_CHECK(hipGetLastError());
+      const float ms = t.end();
+      if (r == 0 || ms < best)
+        best = ms;
+    }
+    *lookups_per_second = (double)n / ((double)best * 1e-3);
+    return (int)GRX_OK;
+  });
+}
 
 int grx_measure_copy_bandwidth(grx_context_t ctx, size_t bytes, int repeats, double* gbps) {
   if (!ctx || !gbps || bytes < 4096 || repeats < 1)

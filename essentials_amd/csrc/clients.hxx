@@ -99,7 +99,9 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
                                                          edge_t const& edge,
                                                          weight_t const& weight) -> bool {
-      // first arrival wins; later arrivals of the same level see an equal depth
+      // first arrival wins; later arrivals of the same level see an equal depth.  (Measured
+      // neutral in front of this test: a dense "seen" bitmap, and a batched read-only pre-test of
+      // a lane's four in-flight edges -- DESIGN.md section 5.)
       return next_level < math::atomic::min(&depth[dst], next_level);
     };
     operators::advance::execute<lb>(G, E, visit, context);

@@ -93,8 +93,18 @@ class SingleRunner:
                 best = st
         nbytes = bfs_algorithmic_bytes(best.edges_traversed, best.vertices_reached)
         achieved = nbytes / (best.advance_kernel_ms * 1e-3) / 1e9
+        # the ceiling this functor actually sits under: one random 4-B label lookup per edge
+        # (grx_measure_gather_rate: table[column[i]] over the graph's own column array)
+        gather = {m: self.ctx.gather_rate(self.g, mode) / 1e9 for m, mode in (("agent_scope", 1), ("plain", 0))}
+        kernel_gteps = best.edges_traversed / (best.advance_kernel_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "gather_roof": {"unit": "G lookups/s", "agent_scope_loads": gather["agent_scope"],
+                                "plain_loads": gather["plain"],
+                                "frac_of_gather_roof": kernel_gteps / max(gather.values()),
+                                "note": "measured live: acc += table[column[i]] over all edges of this "
+                                        "graph (4-B entries, |V| of them), no frontier logic, atomics "
+                                        "or output -- the ceiling of any label-testing advance"},
                 "kernel": "block_mapped_kernel+chunk_kernel (BFS advance, all levels of one traversal)",
                 "algorithmic_bytes": nbytes, "kernel_ms": best.advance_kernel_ms,
                 "launches": best.advance_launches, "enact_ms": best.elapsed_ms,

@@ -259,6 +259,15 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
  * the achievable-HBM roof quoted beside the 8 TB/s vendor peak. Returns GB/s. */
 int grx_measure_copy_bandwidth(grx_context_t ctx, size_t bytes, int repeats, double* gbps);
 
+/* Random-gather ceiling of a graph: acc += table[column_indices[i]] over ALL its edges (4-B table
+ * entries, one per vertex) -- the access every label-testing advance functor shares (reference
+ * bfs.hxx:92-107, sssp.hxx:95-113), without frontier logic, atomics or output.  mode 0 = plain
+ * (L1-cached) loads, 1 = the agent-scope loads math::atomic::min pre-tests with.  Best of
+ * `repeats`; returns lookups (= edges) per second: the roof MTEPS of a push traversal is
+ * measured against. */
+int grx_measure_gather_rate(grx_context_t ctx, grx_graph_t g, int mode, int repeats,
+                            double* lookups_per_second);
+
 #ifdef __cplusplus
 }
 #endif

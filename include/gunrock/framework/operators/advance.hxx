@@ -64,7 +64,11 @@ template <int header_only = 0>  // a template so that every translation unit may
 __global__ void publish_counters_kernel(unsigned long long* counters, unsigned long long* mirror,
                                         unsigned long long sequence) {
   const int i = threadIdx.x;
+#ifdef GRX_TILE_TIMING
+  if (i < 31 && i != 16) {  // diagnostic build: slots 20..28 carry the tile kernel's phase clocks
+#else
   if (i < 16) {
+#endif
     // the counters were updated by device-scope atomics (memory side); read and clear them
     // with cache-bypassing accesses instead of trusting what this XCD's L2 may still hold
     mirror[i] = __hip_atomic_exchange(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -196,11 +200,33 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
   if (std::getenv("GRX_DEBUG"))
     std::fprintf(stderr, "[grx] advance done: out %llu chunks %llu next_work %llu\n", m[k::C_OUT],
                  m[k::C_CHUNKS], m[k::C_NEXT_WORK]);
+#ifdef GRX_TILE_TIMING
+  if (std::getenv("GRX_DEBUG") && m[26])
+    std::fprintf(stderr,
+                 "[grx] tile timing (us, mean per workgroup of %llu): stage %.1f edges %.1f drain %.1f "
+                 "total %.1f max-total %.1f | tiles/wg %.2f iters/wg %.2f\n",
+                 m[26], m[20] / 100.0 / m[26], m[21] / 100.0 / m[26], m[25] / 100.0 / m[26],
+                 m[24] / 100.0 / m[26], m[28] / 100.0, (double)m[23] / m[26], (double)m[22] / m[26]);
+#endif
   error::throw_if_exception(m[k::C_OVERFLOW] != 0,
                             "advance: output frontier capacity exceeded");
   output.set_number_of_elements(holes ? (std::size_t)total : (std::size_t)m[k::C_OUT]);
   if (!holes)
     output.set_work_hint(m[k::C_NEXT_WORK]);
+}
+
+/// Input slots per tile of the block_mapped kernel.
+inline unsigned tile_width_for(std::size_t n_in, unsigned persistent_workgroups,
+                               gcuda::standard_context_t& ctx) {
+  unsigned w = ctx.options().tile_width;
+  if (w == 0)
+    w = (unsigned)k::ADV_BLOCK;
+  unsigned p = 16;
+  while (p * 2 <= w && p * 2 <= (unsigned)k::ADV_BLOCK)
+    p *= 2;
+  (void)n_in;
+  (void)persistent_workgroups;
+  return p;
 }
 
 /// Device chunk queue sized for every hub of this call: a list of d edges makes at most
@@ -274,8 +300,9 @@ void execute(graph_t& G,
   const unsigned hub_threshold = context.options().hub_threshold;
   const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
   unsigned long long* counters = context.workspace().counters();
-  const std::size_t n_tiles = (n_in + k::ADV_BLOCK - 1) / k::ADV_BLOCK;
   const unsigned persistent = (unsigned)context.compute_units() * context.options().tile_blocks_per_cu;
+  const unsigned tile_width = detail::tile_width_for(n_in, persistent, context);
+  const std::size_t n_tiles = (n_in + tile_width - 1) / tile_width;
   const unsigned grid = (unsigned)(n_tiles < persistent ? n_tiles : persistent);
   vertex_t* out_ptr = has_out ? output.data() : nullptr;
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
@@ -285,12 +312,12 @@ void execute(graph_t& G,
     k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,
-                                                      hub_threshold, chunk_edges);
+                                                      hub_threshold, chunk_edges, nullptr, tile_width);
   } else {
     k::block_mapped_kernel<false, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,
-                                                      hub_threshold, chunk_edges);
+                                                      hub_threshold, chunk_edges, nullptr, tile_width);
     if (max_deg >= hub_threshold) {
       const unsigned chunk_grid =
           (unsigned)context.compute_units() * context.options().chunk_blocks_per_cu;

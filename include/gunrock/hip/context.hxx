@@ -160,6 +160,8 @@ struct operator_options_t {
   /// Persistent workgroups per CU for the tile / chunk kernels.
   unsigned tile_blocks_per_cu = 8;
   unsigned chunk_blocks_per_cu = 4;
+  /// Input slots per tile of the block_mapped kernel (power of two <= 256); 0 = chosen per call.
+  unsigned tile_width = 0;
   /// Hub chunks are taken by single wavefronts instead of whole workgroups.
   bool wave_chunks = false;
   /// Test hook: cap the hub chunk queue (0 = sized per call) to force the overflow path, in
@@ -264,6 +266,8 @@ class standard_context_t {
       options_.tile_blocks_per_cu = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_CHUNK_BLOCKS_PER_CU"))
       options_.chunk_blocks_per_cu = (unsigned)std::atoi(e);
+    if (const char* e = std::getenv("GRX_TILE_WIDTH"))
+      options_.tile_width = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_WAVE_CHUNKS"))
       options_.wave_chunks = std::atoi(e) != 0;
     if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))

@@ -104,6 +104,45 @@ struct wave_queue_t {
     fill = 0;
   }
 
+  /// flush() that also sums degree_of(entry) into `work`: the degrees of a whole queue are
+  /// looked up here, 8 independent loads per lane, instead of one dependent lookup behind each
+  /// accepted edge inside the expansion loop.
+  template <typename degree_f>
+  __device__ __forceinline__ void flush_summing(vertex_t* out, std::size_t capacity,
+                                                unsigned long long* counters, degree_f degree_of) {
+    if (fill == 0)
+      return;
+    const int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0)
+      base = atomicAdd(&counters[cursor], (unsigned long long)fill);
+    base = __shfl(base, 0, wave_size);
+    for (unsigned j = lane; j < fill; j += wave_size) {
+      const vertex_t x = q[j];
+      work += degree_of(x);
+      if (base + j < capacity)
+        out[base + j] = x;
+      else
+        counters[C_OVERFLOW] = 1ull;
+    }
+    fill = 0;
+  }
+
+  /// push() without a degree: pair with flush_summing / drain_block_summing.
+  template <typename degree_f>
+  __device__ __forceinline__ void push_deferred(bool keep, vertex_t value, vertex_t* out,
+                                                std::size_t capacity, unsigned long long* counters,
+                                                degree_f degree_of) {
+    unsigned long long m = __ballot(keep);
+    if (m == 0)
+      return;
+    if (fill + wave_size > (unsigned)ADV_WQCAP)
+      flush_summing(out, capacity, counters, degree_of);
+    if (keep)
+      q[fill + rank_in_mask(m)] = value;
+    fill += (unsigned)__popcll(m);
+  }
+
   /// All 64 lanes must call (keep=false for idle lanes).
   __device__ __forceinline__ void push(bool keep, vertex_t value, unsigned degree, vertex_t* out,
                                        std::size_t capacity, unsigned long long* counters) {
@@ -155,6 +194,19 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
   wq.fill = 0;
   wq.work = 0;
   __syncthreads();
+}
+
+/// drain_block for queues filled with push_deferred: the degrees of the leftover entries are
+/// looked up first.
+template <typename vertex_t, typename degree_f>
+__device__ __forceinline__ void drain_block_summing(wave_queue_t<vertex_t>& wq, unsigned* s_counts,
+                                                    unsigned long long* s_base, vertex_t* out,
+                                                    std::size_t capacity,
+                                                    unsigned long long* counters,
+                                                    degree_f degree_of) {
+  for (unsigned j = lane_id(); j < wq.fill; j += wave_size)
+    wq.work += degree_of(wq.q[j]);
+  drain_block(wq, s_counts, s_base, out, capacity, counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -238,7 +290,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                         unsigned long long chunk_capacity,
                         unsigned hub_threshold,
                         unsigned chunk_edges,
-                        const unsigned long long* n_in_device = nullptr) {
+                        const unsigned long long* n_in_device = nullptr,
+                        unsigned tile_width = ADV_BLOCK) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   constexpr bool PACKED = HAS_OUT && !HOLES;
@@ -259,29 +312,61 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int tid = threadIdx.x;
   const int wave = tid / wave_size;
   wave_queue_t<vertex_t> wq{s_queue + (PACKED ? wave * ADV_WQCAP : 0), 0u, 0ull};
+  auto degree_of = [&G](vertex_t x) -> unsigned { return (unsigned)G.get_number_of_neighbors(x); };
 
-  const unsigned long long n_tiles = (n_in + ADV_BLOCK - 1) / ADV_BLOCK;
-  unsigned long long tile = blockIdx.x;
-  if (DYNAMIC) {
-    if (tid == 0)
-      s_tile = atomicAdd(&counters[C_TILE], 1ull);
-    __syncthreads();
-    tile = s_tile;
+  // a tile = tile_width (<= ADV_BLOCK) consecutive input slots, one per lane; narrow tiles bound
+  // the work of one tile (tile_width * hub_threshold edges) when there are few of them
+  const unsigned long long n_tiles = (n_in + tile_width - 1) / tile_width;
+
+  // Tiles are claimed two ahead and their operands fetched one tile early: while this workgroup
+  // expands tile t, the row offsets of tile t+1 and the input slots of tile t+2 are in flight.
+  // Under load a dependent global access costs a full trip through queues that the expansion's
+  // gathers keep deep (~10 us on RMAT-22 level 2), and a tile needs two of them before its first
+  // edge: fetched in line they were most of the kernel's time.
+  auto claim = [&](unsigned long long after) -> unsigned long long {
+    if (DYNAMIC) {
+      if (tid == 0)
+        s_tile = atomicAdd(&counters[C_TILE], 1ull);
+      __syncthreads();
+      const unsigned long long t = s_tile;
+      __syncthreads();  // s_tile is rewritten by the next claim
+      return t;
+    }
+    return after + gridDim.x;
+  };
+  auto slot_vertex = [&](unsigned long long t) -> vertex_t {
+    const std::size_t idx = (std::size_t)t * tile_width + tid;
+    if (t < n_tiles && (unsigned)tid < tile_width && idx < n_in)
+      return (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+    return gunrock::numeric_limits<vertex_t>::invalid();
+  };
+
+#ifdef GRX_TILE_TIMING
+  unsigned long long tt_start = wall_clock64(), tt_stage = 0, tt_edges = 0, tt_iters = 0, tt_tiles = 0;
+#endif
+  unsigned long long tile = DYNAMIC ? claim(0) : (unsigned long long)blockIdx.x;
+  unsigned long long tile1 = claim(tile);
+  vertex_t v = slot_vertex(tile);
+  edge_t first = 0, last = 0;
+  if (util::limits::is_valid(v)) {
+    first = G.get_starting_edge(v);
+    last = G.get_starting_edge(v + 1);
   }
+  vertex_t v1 = slot_vertex(tile1);
 
   while (tile < n_tiles) {
-    // ---- 1. stage the tile: vertex, first edge, degree ----------------------
-    const std::size_t idx = (std::size_t)tile * ADV_BLOCK + tid;
-    vertex_t v = gunrock::numeric_limits<vertex_t>::invalid();
-    edge_t first = 0;
-    unsigned deg = 0;
-    if (idx < n_in) {
-      v = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
-      if (util::limits::is_valid(v)) {
-        first = G.get_starting_edge(v);
-        deg = (unsigned)(G.get_starting_edge(v + 1) - first);
-      }
+    // ---- 1. this tile's operands arrived during the previous one; start the next ones ------
+#ifdef GRX_TILE_TIMING
+    const unsigned long long tt0 = wall_clock64();
+#endif
+    const unsigned deg = (unsigned)(last - first);
+    const unsigned long long tile2 = claim(tile1);
+    edge_t first1 = 0, last1 = 0;
+    if (util::limits::is_valid(v1)) {
+      first1 = G.get_starting_edge(v1);
+      last1 = G.get_starting_edge(v1 + 1);
     }
+    const vertex_t v2 = slot_vertex(tile2);
     // ---- 2. hubs leave the tile as equal chunks; one reservation per tile ----
     //         (degree, chunk count) are scanned together, packed in 64 bits
     unsigned my_chunks = 0;
@@ -330,6 +415,12 @@ __global__ void __launch_bounds__(ADV_BLOCK)
       s_base = total ? atomicAdd(&counters[C_OUT], (unsigned long long)total) : 0ull;
     __syncthreads();
 
+#ifdef GRX_TILE_TIMING
+    const unsigned long long tt1 = wall_clock64();
+    tt_stage += tt1 - tt0;
+    tt_iters += (total + ADV_BLOCK * ADV_UNROLL - 1) / (ADV_BLOCK * ADV_UNROLL);
+    ++tt_tiles;
+#endif
     // ---- 3. stride the concatenated neighbour lists -------------------------
     for (unsigned i0 = 0; i0 < total; i0 += ADV_BLOCK * ADV_UNROLL) {
       vertex_t src[ADV_UNROLL], nbr[ADV_UNROLL];
@@ -363,27 +454,41 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                 counters[C_OVERFLOW] = 1ull;
             }
           } else {
-            unsigned dn = 0;
-            if (keep)
-              dn = (unsigned)G.get_number_of_neighbors(nbr[k]);
-            wq.push(keep, nbr[k], dn, output, capacity, counters);
+            wq.push_deferred(keep, nbr[k], output, capacity, counters, degree_of);
           }
         }
       }
     }
     __syncthreads();  // the LDS tile arrays are rewritten by the next tile
+#ifdef GRX_TILE_TIMING
+    tt_edges += wall_clock64() - tt1;
+#endif
 
-    if (DYNAMIC) {
-      if (tid == 0)
-        s_tile = atomicAdd(&counters[C_TILE], 1ull);
-      __syncthreads();
-      tile = s_tile;
-    } else {
-      tile += gridDim.x;
-    }
+    tile = tile1;
+    tile1 = tile2;
+    v = v1;
+    first = first1;
+    last = last1;
+    v1 = v2;
   }
+#ifdef GRX_TILE_TIMING
+  const unsigned long long tt_loop_end = wall_clock64();
+#endif
   if constexpr (PACKED)
-    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+    drain_block_summing(wq, s_counts, &s_base, output, capacity, counters, degree_of);
+#ifdef GRX_TILE_TIMING
+  if (tid == 0) {  // 100 MHz ticks, summed over workgroups (slots 20..27), max total in 28
+    const unsigned long long tt_end = wall_clock64();
+    atomicAdd(&counters[20], tt_stage);
+    atomicAdd(&counters[21], tt_edges);
+    atomicAdd(&counters[22], tt_iters);
+    atomicAdd(&counters[23], tt_tiles);
+    atomicAdd(&counters[24], tt_end - tt_start);
+    atomicAdd(&counters[25], tt_end - tt_loop_end);
+    atomicAdd(&counters[26], 1ull);
+    atomicMax(&counters[28], tt_end - tt_start);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -408,6 +513,7 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 
   const int tid = threadIdx.x;
   wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? (tid / wave_size) * ADV_WQCAP : 0), 0u, 0ull};
+  auto degree_of = [&G](vertex_t x) -> unsigned { return (unsigned)G.get_number_of_neighbors(x); };
 
   // the queue length: still in the device counter when this launch directly follows the
   // producer, or passed by a host that already fetched (and thereby cleared) the counters
@@ -442,16 +548,13 @@ __global__ void __launch_bounds__(ADV_BLOCK)
         if (live[k])
           keep = op(source, nbr[k], eid[k], wgt[k]);
         if constexpr (HAS_OUT) {
-          unsigned dn = 0;
-          if (keep)
-            dn = (unsigned)G.get_number_of_neighbors(nbr[k]);
-          wq.push(keep, nbr[k], dn, output, capacity, counters);
+          wq.push_deferred(keep, nbr[k], output, capacity, counters, degree_of);
         }
       }
     }
   }
   if constexpr (HAS_OUT)
-    drain_block(wq, s_counts, &s_base, output, capacity, counters);
+    drain_block_summing(wq, s_counts, &s_base, output, capacity, counters, degree_of);
 }
 
 // ---------------------------------------------------------------------------

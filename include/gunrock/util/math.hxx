@@ -182,6 +182,18 @@ __host__ __device__ __forceinline__ type_t exch(type_t* address, type_t value) {
 #endif
 }
 
+/// Atomic OR, returns the previous word (not in the reference; used for dense "seen" bitmaps).
+template <typename type_t>
+__host__ __device__ __forceinline__ type_t bit_or(type_t* address, type_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ::atomicOr(address, value);
+#else
+  type_t old = *address;
+  *address = old | value;
+  return old;
+#endif
+}
+
 }  // namespace atomic
 }  // namespace math
 
