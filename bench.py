@@ -182,6 +182,7 @@ def main():
         pmc = json.load(open(pmc_path))
         roof["traffic"] = pmc["traffic_bytes_per_traversal"]
         roof["l2_busy_frac"] = pmc.get("l2", {}).get("busy_frac_all_bfs_advance_dispatches")
+        roof["l2_hit_rate"] = pmc.get("l2", {}).get("hit_rate_bfs_advance")
         roof["traffic_note"] = ("bytes per traversal = (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 "
                                 "--pmc passes (profiles/latest_pmc.json); lower bound without the x2: %d"
                                 % pmc["traffic_bytes_per_traversal_lower_bound"])
