@@ -171,13 +171,14 @@ _SIGNATURES = {
     "grx_partitioned_expand": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, C.c_int32,
                                          _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64,
                                          C.POINTER(C.c_int64)]),
-    "grx_partitioned_admit": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, _VP, C.c_int32,
-                                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int64,
-                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "grx_partitioned_level_bitmap": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int64]),
+    "grx_partitioned_admit": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64, _VP, C.c_int32, _VP,
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "grx_partitioned_step": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, _VP, _VP,
-                                       C.c_int32, _VP, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
-                                       C.c_int32, _VP, C.c_int64, _VP, _VP, C.c_int64, _VP,
-                                       C.c_int64]),
+                                       C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                       C.c_int32, C.c_int32, _VP, C.c_int64, _VP, _VP, C.c_int64,
+                                       _VP, C.c_int64]),
     "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "grx_measure_gather_rate": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }

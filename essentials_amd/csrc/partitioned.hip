@@ -157,6 +157,88 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+/// Dense BFS exchange: bit v of `words` = (depth[v] == level), i.e. "this rank discovered v in
+/// the superstep that just ran".  One coalesced ballot pass, no atomics; V/8 bytes per rank
+/// travel instead of 8 bytes per discovery.
+__global__ void __launch_bounds__(256)
+    level_bitmap_kernel(const int32_t* depth, int64_t n, int32_t level, unsigned long long* words) {
+  const int64_t padded = (n + 63) / 64 * 64;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < padded; i += (int64_t)gridDim.x * 256) {
+    const bool in = i < n && depth[i] == level;
+    const unsigned long long m = __ballot(in);
+    if ((threadIdx.x & 63) == 0)
+      words[i / 64] = m;
+  }
+}
+
+/// Admission from the gathered level bitmaps (world x words_per_rank): the union of all ranks'
+/// discoveries gets depth = level in this replica; the owned ones form the next frontier
+/// (ascending).  A vertex reached in an earlier level is in nobody's bitmap (replicas agree after
+/// every superstep), so every owned set bit is appended exactly once.
+__global__ void __launch_bounds__(256)
+    admit_bitmap_kernel(int32_t* depth, int64_t n, int32_t level, const unsigned long long* recv,
+                        int32_t world, int64_t words_per_rank, int32_t lo, int32_t hi, int32_t* next,
+                        unsigned long long next_capacity, unsigned long long* next_count,
+                        unsigned long long* overflow) {
+  __shared__ unsigned wave_totals[256 / hip::wave_size + 1];
+  __shared__ unsigned long long s_base;
+  const int64_t n_words = (n + 63) / 64;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t rounds = (n_words + stride - 1) / stride;
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t w = r * stride + blockIdx.x * 256ll + threadIdx.x;
+    unsigned long long m = 0;
+    if (w < n_words)
+      for (int32_t p = 0; p < world; ++p)
+        m |= recv[(int64_t)p * words_per_rank + w];
+    // owned part of this word: vertices [lo, hi)
+    unsigned long long own = m;
+    const int64_t v0 = w * 64;
+    if (v0 + 64 <= lo || v0 >= hi) {
+      own = 0;
+    } else {
+      if (v0 < lo)
+        own &= ~0ull << (lo - v0);
+      if (v0 + 64 > hi)
+        own &= ~0ull >> (v0 + 64 - hi);
+    }
+    unsigned total = 0;
+    unsigned at = hip::block_exclusive_sum<256>((unsigned)__popcll(own), total, wave_totals);
+    if (total) {  // workgroup-uniform
+      if (threadIdx.x == 0)
+        s_base = atomicAdd(next_count, (unsigned long long)total);
+      __syncthreads();
+    }
+    unsigned long long bits = m;
+    while (bits) {
+      const int b = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      const int64_t v = v0 + b;
+      if (depth[v] > level)
+        depth[v] = level;
+    }
+    if (total) {
+      unsigned long long pos = s_base + at;
+      while (own) {
+        const int b = __ffsll((long long)own) - 1;
+        own &= own - 1;
+        if (pos < next_capacity)
+          next[pos] = (int32_t)(v0 + b);
+        else
+          *overflow = 1ull;
+        ++pos;
+      }
+      __syncthreads();  // s_base is rewritten by the next round
+    }
+  }
+}
+
+inline unsigned bitmap_grid(int64_t n_items, int cus) {
+  const int64_t g = (n_items + 255) / 256;
+  const int64_t cap = (int64_t)cus * 8;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 template <typename label_t>
 int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_t edge_op,
               label_t* labels, int32_t iparam, const int32_t* d_frontier, int64_t n_frontier,
@@ -301,48 +383,85 @@ int grx_partitioned_expand(grx_context_t ctx, grx_graph_t local, const grx_optio
   });
 }
 
-int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int32_t* d_stamp,
-                          int32_t round, const int64_t* d_recv, int32_t world, int64_t slot,
-                          int32_t me, int32_t lo, int32_t hi, int32_t* d_next, int64_t next_capacity,
-                          int64_t* n_next, int64_t* n_total_found) {
-  if (!ctx || !d_labels || !d_stamp || !d_recv || !d_next || !n_next || world < 1 || slot < 2 ||
-      me < 0 || me >= world)
+int grx_partitioned_level_bitmap(grx_context_t ctx, const int32_t* d_depth, int64_t n_vertices,
+                                 int32_t level, int64_t* d_words, int64_t word_capacity) {
+  if (!ctx || !d_depth || !d_words || n_vertices < 1 || word_capacity < (n_vertices + 63) / 64)
+    return invalid("grx_partitioned_level_bitmap: bad arguments");
+  return guarded([&] {
+    auto& sc = ctx->single();
+    level_bitmap_kernel<<<bitmap_grid(n_vertices, sc.compute_units()), 256, 0, sc.stream()>>>(
+        d_depth, n_vertices, level, reinterpret_cast<unsigned long long*>(d_words));
+    GRX_HIP_CHECK(hipGetLastError());
+    return (int)GRX_OK;
+  });
+}
+
+namespace {
+/// Enqueue the admission of one gather (either format) into next / *next_count.
+void enqueue_admit(gcuda::standard_context_t& sc, int32_t edge_op, int32_t recv_format, void* d_labels,
+                   int64_t n_vertices, int32_t* d_stamp, int32_t round, const int64_t* d_recv,
+                   int32_t world, int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* d_next,
+                   int64_t next_capacity, unsigned long long* next_count,
+                   unsigned long long* overflow) {
+  if (recv_format == GRX_RECV_LEVEL_BITMAP) {
+    const int64_t n_words = (n_vertices + 63) / 64;
+    admit_bitmap_kernel<<<bitmap_grid(n_words, sc.compute_units()), 256, 0, sc.stream()>>>(
+        (int32_t*)d_labels, n_vertices, round + 1,
+        reinterpret_cast<const unsigned long long*>(d_recv), world, slot, lo, hi, d_next,
+        (unsigned long long)next_capacity, next_count, overflow);
+  } else {
+    const int64_t total = (int64_t)world * (slot - 1);
+    const unsigned grid = (unsigned)std::min<int64_t>(
+        std::max<int64_t>((total + APPEND_TILE - 1) / APPEND_TILE, 1), (int64_t)sc.compute_units() * 8);
+    if (edge_op == GRX_OP_BFS)
+      admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
+          (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
+          (unsigned long long)next_capacity, next_count, overflow);
+    else
+      admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
+          (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
+          (unsigned long long)next_capacity, next_count, overflow);
+  }
+  GRX_HIP_CHECK(hipGetLastError());
+}
+
+int check_recv(int32_t edge_op, int32_t recv_format, int64_t n_vertices, int64_t slot) {
+  if (recv_format != GRX_RECV_PAIRS && recv_format != GRX_RECV_LEVEL_BITMAP)
+    return invalid("partitioned: unknown recv_format");
+  if (recv_format == GRX_RECV_LEVEL_BITMAP) {
+    if (edge_op != GRX_OP_BFS)
+      return unsupported("partitioned: the level bitmap exchange carries no labels (BFS only)");
+    if (slot < (n_vertices + 63) / 64)
+      return invalid("partitioned: bitmap slot shorter than ceil(V / 64) words");
+  } else if (slot < 2) {
+    return invalid("partitioned: pair slot needs at least 2 words");
+  }
+  return GRX_OK;
+}
+}  // namespace
+
+int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int64_t n_vertices,
+                          int32_t* d_stamp, int32_t round, const int64_t* d_recv,
+                          int32_t recv_format, int32_t world, int64_t slot, int32_t me, int32_t lo,
+                          int32_t hi, int32_t* d_next, int64_t next_capacity, int64_t* n_next) {
+  if (!ctx || !d_labels || !d_stamp || !d_recv || !d_next || !n_next || world < 1 || me < 0 ||
+      me >= world || n_vertices < 1)
     return invalid("grx_partitioned_admit: bad arguments");
   if (edge_op != GRX_OP_BFS && edge_op != GRX_OP_SSSP)
     return unsupported("grx_partitioned_admit: edge_op must be GRX_OP_BFS or GRX_OP_SSSP");
+  if (int rc = check_recv(edge_op, recv_format, n_vertices, slot))
+    return rc;
   return guarded([&] {
     auto& sc = ctx->single();
     auto& ws = sc.workspace();
     unsigned long long* counters = ws.counters();  // zero between operators (see fetch_counters)
-    const int64_t total = (int64_t)world * (slot - 1);
-    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + APPEND_TILE - 1) / APPEND_TILE, 1),
-                                                      (int64_t)sc.compute_units() * 8);
-    if (edge_op == GRX_OP_BFS)
-      admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
-          (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
-          (unsigned long long)next_capacity, counters + hip::kernels::C_OUT,
-          counters + hip::kernels::C_OVERFLOW);
-    else
-      admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
-          (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_next,
-          (unsigned long long)next_capacity, counters + hip::kernels::C_OUT,
-          counters + hip::kernels::C_OVERFLOW);
-    GRX_HIP_CHECK(hipGetLastError());
+    enqueue_admit(sc, edge_op, recv_format, d_labels, n_vertices, d_stamp, round, d_recv, world, slot,
+                  me, lo, hi, d_next, next_capacity, counters + hip::kernels::C_OUT,
+                  counters + hip::kernels::C_OVERFLOW);
     unsigned long long* m = operators::advance::detail::fetch_counters(sc);
     error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_admit: next frontier capacity exceeded");
     *n_next = (int64_t)m[hip::kernels::C_OUT];
-    if (n_total_found) {
-      // the per-rank counts sit at recv[p * slot]; the host loop already knows them from the
-      // gather, so this is only filled on request
-      std::vector<int64_t> heads((std::size_t)world);
-      GRX_HIP_CHECK(hipMemcpy2D(heads.data(), sizeof(int64_t), d_recv, (std::size_t)slot * 8,
-                                sizeof(int64_t), (std::size_t)world, hipMemcpyDeviceToHost));
-      int64_t t = 0;
-      for (auto h : heads)
-        t += h;
-      *n_total_found = t;
-    }
     return (int)GRX_OK;
   });
 }
@@ -352,16 +471,19 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
  * issues the collective on the same stream and synchronises once, on the gathered counts. */
 int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
                          int32_t edge_op, void* d_labels, int32_t* d_stamp, int32_t* d_sent,
-                         int32_t round, const int64_t* d_recv, int32_t world, int64_t slot,
-                         int32_t me, int32_t lo, int32_t hi, int32_t* d_frontier,
+                         int32_t round, const int64_t* d_recv, int32_t recv_format, int32_t world,
+                         int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* d_frontier,
                          int64_t frontier_capacity, uint64_t* d_frontier_count, int32_t* d_scratch,
                          int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity) {
   if (!ctx || !local || !d_labels || !d_stamp || !d_sent || !d_frontier || !d_frontier_count ||
       !d_scratch || !d_send || send_capacity < 2 || frontier_capacity < 1 || scratch_capacity < 1 ||
-      world < 1 || me < 0 || me >= world || (d_recv && slot < 2))
+      world < 1 || me < 0 || me >= world)
     return invalid("grx_partitioned_step: bad arguments");
   if (edge_op != GRX_OP_BFS && edge_op != GRX_OP_SSSP)
     return unsupported("grx_partitioned_step: edge_op must be GRX_OP_BFS or GRX_OP_SSSP");
+  if (d_recv)
+    if (int rc = check_recv(edge_op, recv_format, local->n_rows, slot))
+      return rc;
   grx_options o;
   grx_default_options(&o);
   if (opt)
@@ -384,18 +506,10 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
     // 1. admit what the other ranks found last superstep -> this superstep's owned frontier
     if (d_recv) {
       GRX_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), sc.stream()));
-      const int64_t total = (int64_t)world * (slot - 1);
-      const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((total + APPEND_TILE - 1) / APPEND_TILE, 1),
-                                                        (int64_t)sc.compute_units() * 8);
-      if (edge_op == GRX_OP_BFS)
-        admit_kernel<int32_t, false><<<grid, 256, 0, sc.stream()>>>(
-            (int32_t*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_frontier,
-            (unsigned long long)frontier_capacity, count_dev, counters + hip::kernels::C_OVERFLOW);
-      else
-        admit_kernel<float, true><<<grid, 256, 0, sc.stream()>>>(
-            (float*)d_labels, d_stamp, round, d_recv, world, slot, me, lo, hi, d_frontier,
-            (unsigned long long)frontier_capacity, count_dev, counters + hip::kernels::C_OVERFLOW);
-      GRX_HIP_CHECK(hipGetLastError());
+      // the gather carries the finds of superstep round - 1
+      enqueue_admit(sc, edge_op, recv_format, d_labels, local->n_rows, d_stamp, round - 1, d_recv,
+                    world, slot, me, lo, hi, d_frontier, frontier_capacity, count_dev,
+                    counters + hip::kernels::C_OVERFLOW);
     }
     // 2. local advance over the owned frontier (duplicate-free: work bounded by the rank's edges)
     graph_type G = local->view();

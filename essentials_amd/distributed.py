@@ -29,6 +29,7 @@ from . import api as ea
 
 HBM_PEAK_GBPS = 8000.0
 OP_BFS, OP_SSSP = int(ea.EdgeOp.bfs), int(ea.EdgeOp.sssp)
+RECV_PAIRS, RECV_LEVEL_BITMAP = 0, 1   # grx_recv_format
 
 
 def bfs_algorithmic_bytes(edges_traversed: int, vertices_reached: int) -> int:
@@ -161,23 +162,29 @@ class HipKernels:
             "grx_partitioned_expand")
         return n.value
 
-    def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
+    def admit(self, op, labels, stamp, rnd, recv, fmt, world, slot, rank, lo, hi, nxt):
         n_next = C.c_int64()
         ea._check(self.lib.grx_partitioned_admit(
-            self.ctx._h, op, labels.data_ptr(), stamp.data_ptr(), rnd, recv.data_ptr(), world, slot,
-            rank, lo, hi, nxt.data_ptr(), nxt.numel(), C.byref(n_next), None),
-            "grx_partitioned_admit")
+            self.ctx._h, op, labels.data_ptr(), labels.numel(), stamp.data_ptr(), rnd,
+            recv.data_ptr(), fmt, world, slot, rank, lo, hi, nxt.data_ptr(), nxt.numel(),
+            C.byref(n_next)), "grx_partitioned_admit")
         return n_next.value
 
+    def level_bitmap(self, depth, level, words) -> None:
+        """words[ceil(V/64)] <- bit v = (depth[v] == level); enqueue-only."""
+        ea._check(self.lib.grx_partitioned_level_bitmap(
+            self.ctx._h, depth.data_ptr(), depth.numel(), level, words.data_ptr(), words.numel()),
+            "grx_partitioned_level_bitmap")
 
-    def step(self, op, labels, stamp, sent, rnd, recv, world, slot, rank, lo, hi, frontier, fcount,
-             scratch, send) -> None:
+    def step(self, op, labels, stamp, sent, rnd, recv, fmt, world, slot, rank, lo, hi, frontier,
+             fcount, scratch, send) -> None:
         """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> advance -> pack."""
         ea._check(self.lib.grx_partitioned_step(
             self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), stamp.data_ptr(),
-            sent.data_ptr(), rnd, recv.data_ptr() if recv is not None else None, world, slot, rank,
-            lo, hi, frontier.data_ptr(), frontier.numel(), fcount.data_ptr(), scratch.data_ptr(),
-            scratch.numel(), send.data_ptr(), send.numel()), "grx_partitioned_step")
+            sent.data_ptr(), rnd, recv.data_ptr() if recv is not None else None, fmt, world, slot,
+            rank, lo, hi, frontier.data_ptr(), frontier.numel(), fcount.data_ptr(),
+            scratch.data_ptr(), scratch.numel(), send.data_ptr(), send.numel()),
+            "grx_partitioned_step")
 
 
 class PartitionedTraversal:
@@ -187,7 +194,7 @@ class PartitionedTraversal:
 
     def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int,
                  local_nnz: int, device, small_slot: int | None = None, fused: bool = True,
-                 stream=None):
+                 stream=None, dense_threshold: int | None = None):
         """fused=True uses kernels.step (one enqueue-only call + one host synchronisation per
         superstep); it needs the engine context and the collectives on ONE stream: pass that
         torch stream as `stream` (the context must have been created on stream.cuda_stream)."""
@@ -212,6 +219,14 @@ class PartitionedTraversal:
         self.fcount = torch.zeros(1, dtype=i64, device=device)
         self.recv = torch.zeros(world * self.slot0, dtype=i64, device=device)
         self._recv_big = None
+        # dense BFS supersteps exchange level bitmaps (V/8 bytes per rank) instead of pairs (8 bytes
+        # per discovery): from V/64 discoveries on some rank the bitmap is the smaller message
+        self.words = (n_global + 63) // 64
+        self.dense_threshold = int(dense_threshold if dense_threshold is not None
+                                   else max(n_global // 64, self.slot0 - 1))
+        self.can_dense = hasattr(kernels, "level_bitmap")
+        self.bits = torch.zeros(self.words, dtype=i64, device=device)
+        self.recv_bits = torch.zeros(world * self.words, dtype=i64, device=device)
         self._backend = dist.get_backend() if dist is not None and world > 1 else None
 
     # -- the collective -------------------------------------------------------------------
@@ -250,12 +265,13 @@ class PartitionedTraversal:
         if labels.is_cuda:
             torch.cuda.current_stream().synchronize()
         t0 = time.perf_counter()
-        rounds = found_total = collectives = 0
-        recv_prev, slot_prev = None, 0
+        rounds = found_total = collectives = dense = 0
+        recv_prev, slot_prev, fmt_prev = None, 0, RECV_PAIRS
         while True:
-            self.k.step(op, labels, self.stamp, self.sent, rounds, recv_prev, self.world, slot_prev,
-                        self.rank, self.lo, self.hi, frontier, self.fcount, self.scratch, self.send)
-            slot = self.slot0
+            self.k.step(op, labels, self.stamp, self.sent, rounds, recv_prev, fmt_prev, self.world,
+                        slot_prev, self.rank, self.lo, self.hi, frontier, self.fcount, self.scratch,
+                        self.send)
+            slot, fmt = self.slot0, RECV_PAIRS
             recv = self.recv
             self._all_gather(recv, self.send[:slot])
             collectives += 1
@@ -264,7 +280,14 @@ class PartitionedTraversal:
             most = int(counts.max())
             if most == 0:
                 break
-            if most > slot - 1:
+            if op == OP_BFS and self.can_dense and most > self.dense_threshold:
+                # every rank takes this branch together (same gathered counts)
+                self.k.level_bitmap(labels, rounds + 1, self.bits)
+                recv, slot, fmt = self.recv_bits, self.words, RECV_LEVEL_BITMAP
+                self._all_gather(recv, self.bits)      # same stream: ordered after the bitmap kernel
+                collectives += 1
+                dense += 1
+            elif most > slot - 1:
                 slot = min(((most + 1 + 4095) // 4096) * 4096, self.send.numel())
                 if self._recv_big is None or self._recv_big.numel() < self.world * slot:
                     self._recv_big = torch.zeros(self.world * slot, dtype=torch.int64,
@@ -273,12 +296,13 @@ class PartitionedTraversal:
                 self._all_gather(recv, self.send[:slot])   # same stream: ordered before the admit
                 collectives += 1
             found_total += int(counts.sum())
-            recv_prev, slot_prev = recv, slot
+            recv_prev, slot_prev, fmt_prev = recv, slot, fmt
             rounds += 1
         if labels.is_cuda:
             torch.cuda.current_stream().synchronize()
         return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
-                "pairs_exchanged": found_total, "collectives": collectives, "fused": True}
+                "pairs_exchanged": found_total, "collectives": collectives, "fused": True,
+                "bitmap_supersteps": dense}
 
     def _run(self, op: int, source: int, labels) -> dict:
         torch = self.torch
@@ -295,7 +319,7 @@ class PartitionedTraversal:
         if labels.is_cuda:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rounds = found_total = collectives = 0
+        rounds = found_total = collectives = dense = 0
         prof = [0.0, 0.0, 0.0, 0.0] if os.environ.get("GRX_PART_PROFILE") else None
         while True:
             ta = time.perf_counter()
@@ -314,7 +338,18 @@ class PartitionedTraversal:
                 prof[1] += tc - tb
             if most == 0:
                 break  # no rank improved anything: every replica is final
-            if most > slot - 1:
+            fmt = RECV_PAIRS
+            if op == OP_BFS and self.can_dense and most > self.dense_threshold:
+                self.k.level_bitmap(labels, rounds + 1, self.bits)
+                if recv.is_cuda:
+                    self.k.ctx.synchronize()       # the engine's stream wrote self.bits
+                recv, slot, fmt = self.recv_bits, self.words, RECV_LEVEL_BITMAP
+                self._all_gather(recv, self.bits)
+                collectives += 1
+                dense += 1
+                if recv.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+            elif most > slot - 1:
                 slot = min(((most + 1 + 4095) // 4096) * 4096, self.send.numel())
                 if self._recv_big is None or self._recv_big.numel() < self.world * slot:
                     self._recv_big = torch.zeros(self.world * slot, dtype=torch.int64,
@@ -327,7 +362,7 @@ class PartitionedTraversal:
                     # make the gathered slots visible before admit (phase 1 is fenced by .cpu())
                     torch.cuda.current_stream().synchronize()
             td = time.perf_counter()
-            n_cur = self.k.admit(op, labels, self.stamp, rounds, recv, self.world, slot,
+            n_cur = self.k.admit(op, labels, self.stamp, rounds, recv, fmt, self.world, slot,
                                  self.rank, self.lo, self.hi, nxt)
             found_total += int(counts.sum())
             if prof is not None:
@@ -338,7 +373,7 @@ class PartitionedTraversal:
         if labels.is_cuda:
             torch.cuda.synchronize()
         out = {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
-               "pairs_exchanged": found_total, "collectives": collectives}
+               "pairs_exchanged": found_total, "collectives": collectives, "bitmap_supersteps": dense}
         if prof is not None:
             out["profile_ms"] = {"expand": prof[0] * 1e3, "gather+counts": prof[1] * 1e3,
                                  "big_gather": prof[2] * 1e3, "admit": prof[3] * 1e3}

@@ -214,6 +214,8 @@ int grx_uniquify(grx_context_t ctx, int32_t algorithm, int32_t best_effort, int3
  *   all-gather of the send slots over RCCL (done by the host: torch.distributed / ncclAllGather)
  *   grx_partitioned_admit    min-combine every other rank's pairs into the replica and append
  *                            the owned, improved vertices to the next input frontier
+ * Dense BFS supersteps (more finds than V/64) exchange per-rank LEVEL BITMAPS instead of pairs
+ * (grx_partitioned_level_bitmap + recv_format GRX_RECV_LEVEL_BITMAP).
  * The host loop and the collective live in essentials_amd/distributed.py. */
 
 /* Rank-local slice of a replicated graph; split points balance EDGES (prefix of row offsets). */
@@ -231,28 +233,46 @@ int grx_partitioned_expand(grx_context_t ctx, grx_graph_t local, const grx_optio
                            const int32_t* d_frontier, int64_t n_frontier, int32_t* d_scratch,
                            int64_t scratch_capacity, int32_t* d_sent_stamp, int64_t* d_send,
                            int64_t send_capacity, int64_t* n_found);
-/* d_recv: int64[world_size * slot] gathered send slots.  Pairs of other ranks are min-combined
- * into d_labels; a vertex is appended to d_next (capacity next_capacity) when it is owned
- * (row_begin <= v < row_end), its label improved (or it is one of this rank's own discoveries)
- * and d_stamp[v] != round (then d_stamp[v] = round: one copy per superstep, like the bypass
- * filter of reference algorithms/sssp.hxx:126-136).  *n_total_found = sum of all ranks' counts. */
-int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int32_t* d_stamp,
-                          int32_t round, const int64_t* d_recv, int32_t world_size, int64_t slot,
-                          int32_t my_rank, int32_t row_begin, int32_t row_end, int32_t* d_next,
-                          int64_t next_capacity, int64_t* n_next, int64_t* n_total_found);
+/* What a gathered buffer holds. */
+typedef enum grx_recv_format {
+  GRX_RECV_PAIRS = 0,        /* per rank: [count | (vertex,label) ...], `slot` words each           */
+  GRX_RECV_LEVEL_BITMAP = 1  /* BFS only, dense supersteps: per rank ceil(V/64) words, bit v = "this
+                                rank discovered v in the superstep"; labels are implied (the level) */
+} grx_recv_format;
 
-/* The same superstep FUSED and enqueue-only (block_mapped schedule): [admit d_recv, the previous
- * gather, into d_frontier / *d_frontier_count ->] advance over d_frontier (its length is read on
- * the DEVICE from *d_frontier_count) -> pack into d_send.  Nothing is awaited: the caller issues
- * the collective on the SAME stream (create the context on that stream) and synchronises once per
- * superstep, on the gathered counts.  d_recv == NULL on the first superstep (the caller preset
- * d_frontier / *d_frontier_count).  Buffer overflows of a step are reported by the next call. */
+/* Dense BFS exchange, enqueue-only: d_words[ceil(V/64)] <- bit v = (d_depth[v] == level).  Called
+ * after a superstep whose finds (level = round + 1) are too many for the pair list: V/8 bytes per
+ * rank travel instead of 8 bytes per discovery. */
+int grx_partitioned_level_bitmap(grx_context_t ctx, const int32_t* d_depth, int64_t n_vertices,
+                                 int32_t level, int64_t* d_words, int64_t word_capacity);
+
+/* d_recv: int64[world_size * slot] gathered send slots (recv_format says what they hold).
+ * GRX_RECV_PAIRS: pairs of other ranks are min-combined into d_labels; a vertex is appended to
+ * d_next (capacity next_capacity) when it is owned (row_begin <= v < row_end), its label improved
+ * (or it is one of this rank's own discoveries) and d_stamp[v] != round (then d_stamp[v] = round:
+ * one copy per superstep, like the bypass filter of reference algorithms/sssp.hxx:126-136).
+ * GRX_RECV_LEVEL_BITMAP: every vertex in the union of the bitmaps gets depth round + 1; the owned
+ * ones are appended (ascending).  `round` = the superstep whose finds were gathered. */
+int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, int64_t n_vertices,
+                          int32_t* d_stamp, int32_t round, const int64_t* d_recv,
+                          int32_t recv_format, int32_t world_size, int64_t slot, int32_t my_rank,
+                          int32_t row_begin, int32_t row_end, int32_t* d_next,
+                          int64_t next_capacity, int64_t* n_next);
+
+/* The same superstep FUSED and enqueue-only (block_mapped schedule): [admit d_recv, the gather of
+ * superstep round - 1, into d_frontier / *d_frontier_count ->] advance over d_frontier (its length
+ * is read on the DEVICE from *d_frontier_count) -> pack into d_send.  Nothing is awaited: the
+ * caller issues the collective on the SAME stream (create the context on that stream) and
+ * synchronises once per superstep, on the gathered counts.  d_recv == NULL on the first superstep
+ * (the caller preset d_frontier / *d_frontier_count).  Buffer overflows of a step are reported by
+ * the next call. */
 int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
                          int32_t edge_op, void* d_labels, int32_t* d_stamp, int32_t* d_sent_stamp,
-                         int32_t round, const int64_t* d_recv, int32_t world_size, int64_t slot,
-                         int32_t my_rank, int32_t row_begin, int32_t row_end, int32_t* d_frontier,
-                         int64_t frontier_capacity, uint64_t* d_frontier_count, int32_t* d_scratch,
-                         int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity);
+                         int32_t round, const int64_t* d_recv, int32_t recv_format,
+                         int32_t world_size, int64_t slot, int32_t my_rank, int32_t row_begin,
+                         int32_t row_end, int32_t* d_frontier, int64_t frontier_capacity,
+                         uint64_t* d_frontier_count, int32_t* d_scratch, int64_t scratch_capacity,
+                         int64_t* d_send, int64_t send_capacity);
 
 /* ---- measurement helpers ------------------------------------------------- */
 /* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:

@@ -20,8 +20,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from essentials_amd.distributed import (OP_BFS, OP_SSSP, PartitionedTraversal,  # noqa: E402
-                                        partition_bounds)
+from essentials_amd.distributed import (OP_BFS, OP_SSSP, RECV_LEVEL_BITMAP,  # noqa: E402
+                                        PartitionedTraversal, partition_bounds)
 
 
 class NumpyKernels:
@@ -56,15 +56,34 @@ class NumpyKernels:
             s[1:1 + k] = (bits << 32) | f
         return len(found)
 
-    def step(self, op, labels, stamp, sent, rnd, recv, world, slot, rank, lo, hi, frontier, fcount,
-             scratch, send):
-        """grx_partitioned_step: admit the previous gather, advance, pack -- no result returned."""
+    def step(self, op, labels, stamp, sent, rnd, recv, fmt, world, slot, rank, lo, hi, frontier,
+             fcount, scratch, send):
+        """grx_partitioned_step: admit the gather of superstep rnd - 1, advance, pack."""
         if recv is not None:
-            fcount[0] = self.admit(op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, frontier)
+            fcount[0] = self.admit(op, labels, stamp, rnd - 1, recv, fmt, world, slot, rank, lo, hi,
+                                   frontier)
         self.expand(op, labels, rnd, frontier, int(fcount[0]), scratch, sent, send)
 
-    def admit(self, op, labels, stamp, rnd, recv, world, slot, rank, lo, hi, nxt):
-        lab, st, r, out = labels.numpy(), stamp.numpy(), recv.numpy().reshape(world, slot), nxt.numpy()
+    def level_bitmap(self, depth, level, words):
+        """grx_partitioned_level_bitmap: bit v = (depth[v] == level)."""
+        d = depth.numpy()
+        bits = np.zeros(len(words) * 64, np.uint8)
+        bits[:len(d)] = d == level
+        words.numpy()[:] = np.packbits(bits, bitorder="little").view(np.int64)
+
+    def admit(self, op, labels, stamp, rnd, recv, fmt, world, slot, rank, lo, hi, nxt):
+        lab, st, out = labels.numpy(), stamp.numpy(), nxt.numpy()
+        if fmt == RECV_LEVEL_BITMAP:
+            assert op == OP_BFS
+            r = recv.numpy().reshape(world, slot)
+            union = np.bitwise_or.reduce(r, axis=0)
+            bits = np.unpackbits(union.view(np.uint8), bitorder="little")[:len(lab)].astype(bool)
+            lab[bits & (lab > rnd + 1)] = rnd + 1
+            mine = np.nonzero(bits)[0]
+            mine = mine[(mine >= lo) & (mine < hi)]
+            out[:len(mine)] = mine
+            return len(mine)
+        r = recv.numpy().reshape(world, slot)
         n = 0
         for p in range(world):
             cnt = int(r[p, 0])
@@ -86,7 +105,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir, fused=True):
+def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir, fused=True,
+            dense_threshold=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -97,7 +117,7 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
     lo, hi = b[rank], b[rank + 1]
     k = NumpyKernels(Ap, np.ascontiguousarray(Aj), np.ascontiguousarray(Ax), lo, hi)
     trav = PartitionedTraversal(k, dist, rank, world, n, lo, hi, int(Ap[hi] - Ap[lo]), "cpu",
-                                small_slot=small_slot, fused=fused)
+                                small_slot=small_slot, fused=fused, dense_threshold=dense_threshold)
     ok = True
     why = []
     for s in sources:
@@ -114,18 +134,22 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
         reached = int((want != 2**31 - 1).sum())
         if st["collectives"] < st["supersteps"] or (reached > 1 and st["supersteps"] < 2):
             ok = False; why.append(f"stats {s}: {st}")
+        if dense_threshold is not None and reached > 8 * dense_threshold and not st["bitmap_supersteps"]:
+            ok = False; why.append(f"no bitmap superstep for {s}: {st}")
     open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").write(str(why))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,small_slot,fused", [(2, None, True), (2, 8, True), (3, 64, True),
-                                                    (2, 8, False)])
-def test_partitioned_traversal_gloo(tmp_path, world, small_slot, fused):
+@pytest.mark.parametrize("world,small_slot,fused,dense", [(2, None, True, None), (2, 8, True, None),
+                                                          (3, 64, True, None), (2, 8, False, None),
+                                                          (2, 8, True, 4), (3, 8, False, 4)])
+def test_partitioned_traversal_gloo(tmp_path, world, small_slot, fused, dense):
     """small_slot 8 / 64 forces the second (big-slot) all-gather on the wide levels; fused=True is
-    the one-call-per-superstep loop bench.py uses, False the two-call (expand / admit) loop."""
+    the one-call-per-superstep loop bench.py uses, False the two-call (expand / admit) loop;
+    dense=4 makes BFS supersteps with more than 4 finds exchange level bitmaps."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path), fused),
+    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path), fused, dense),
              nprocs=world, join=True)
     names = sorted(os.listdir(tmp_path))
     notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}

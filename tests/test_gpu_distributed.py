@@ -57,15 +57,19 @@ def test_partitioned_world1_matches_oracle(oracle):
     ctx = ea.Context(0, stream=stream.cuda_stream)      # the fused loop needs ONE stream
     g = ea.Graph.rmat(ctx, 14, 16, 1, 7)
     Ap, Aj, Ax = g.to_host()
-    for small_slot, fused in ((None, True), (16, True), (16, False)):
+    # dense: finds per superstep above which BFS exchanges level bitmaps; 1 << 30 = never
+    for small_slot, fused, dense in ((None, True, None), (16, True, 1 << 30), (16, False, 1 << 30),
+                                     (16, True, 8), (16, False, 8)):
         trav = PartitionedTraversal(HipKernels(ctx, g), None, 0, 1, g.n_rows, 0, g.n_rows, g.nnz,
-                                    "cuda:0", small_slot=small_slot, fused=fused, stream=stream)
+                                    "cuda:0", small_slot=small_slot, fused=fused, stream=stream,
+                                    dense_threshold=dense)
         assert trav.fused == fused
         for s in (0, 7217):
             depth = torch.empty(g.n_rows, dtype=torch.int32, device="cuda")
             st = trav.run(OP_BFS, s, depth)
             want, _ = oracle.bfs_heap(Ap, Aj, s)
-            assert (depth.cpu().numpy() == want).all()
+            assert (depth.cpu().numpy() == want).all(), (small_slot, fused, dense, s)
+            assert (st["bitmap_supersteps"] > 0) == (dense == 8), st
             dist_ = torch.empty(g.n_rows, dtype=torch.float32, device="cuda")
             trav.run(OP_SSSP, s, dist_)
             wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, s)
@@ -94,19 +98,24 @@ def _rank(rank, world, port, scale, out_dir):
                                                       C.byref(hi)), "partition")
     local = ea.Graph(h)
     notes = []
-    for lb, small_slot in ((ea.LoadBalance.block_mapped, None), (ea.LoadBalance.block_mapped, 64),
-                           (ea.LoadBalance.merge_path, None), (ea.LoadBalance.merge_path, 64)):
-        # block_mapped: the fused one-call superstep; merge_path: the two-call loop
+    for lb, small_slot, dense in ((ea.LoadBalance.block_mapped, None, None),
+                                  (ea.LoadBalance.block_mapped, 64, 1 << 30),
+                                  (ea.LoadBalance.block_mapped, 64, 32),
+                                  (ea.LoadBalance.merge_path, None, None),
+                                  (ea.LoadBalance.merge_path, 64, 1 << 30),
+                                  (ea.LoadBalance.merge_path, 64, 32)):
+        # block_mapped: the fused one-call superstep; merge_path: the two-call loop;
+        # dense 32: BFS supersteps with more finds exchange level bitmaps
         trav = PartitionedTraversal(HipKernels(ctx, local, ea.Options(load_balance=lb)), dist, rank,
                                     world, full.n_rows, lo.value, hi.value, local.nnz, "cuda:0",
                                     small_slot=small_slot, fused=(lb == ea.LoadBalance.block_mapped),
-                                    stream=stream)
+                                    stream=stream, dense_threshold=dense)
         for s in (0, 1830):
             depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
             trav.run(OP_BFS, s, depth)
             want, _ = o.bfs_heap(Ap, Aj, s)
             if not (depth.cpu().numpy() == want).all():
-                notes.append(f"bfs {s} {lb.name} {small_slot}")
+                notes.append(f"bfs {s} {lb.name} {small_slot} {dense}")
             d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
             trav.run(OP_SSSP, s, d)
             wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
