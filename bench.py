@@ -211,7 +211,7 @@ def main():
         out["bfs_direction_optimized"] = runner.bfs_direction_optimized(
             sources[a.warmup:a.warmup + min(a.steps, 8)], lb)
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # timed on the host cores at N = 1 only
             Ap, Aj, Ax = runner.host_csr()
             out["cpu_baseline"] = cpu_baseline(Ap, Aj, Ax, a.algo)
             if "bfs" in a.algo:

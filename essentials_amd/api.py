@@ -356,6 +356,13 @@ class Graph:
                                                      ax.ctypes.data), "grx_graph_copy_to_host")
         return ap, aj[: self.nnz], ax[: self.nnz]
 
+    def offsets_to_host(self):
+        """Row offsets only (4 (V + 1) bytes; to_host() moves 8 bytes per edge as well)."""
+        ap = np.empty(self.n_rows + 1, np.int32)
+        _check(load_library().grx_graph_copy_to_host(self._h, ap.ctypes.data, None, None),
+               "grx_graph_copy_to_host")
+        return ap
+
     def close(self) -> None:
         if self._h:
             load_library().grx_graph_destroy(self._h)

@@ -200,6 +200,7 @@ extern "C" int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph
     GRX_HIP_CHECK(hipStreamSynchronize(s));
     r->adopt();
     *out = r.release();
+    hip::block_cache_t::instance().trim();  // the sort's key buffers, see grx_graph_rmat
     return (int)GRX_OK;
   });
 }
@@ -211,6 +212,9 @@ extern "C" int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_f
     return invalid("grx_graph_rmat: NULL argument");
   return guarded([&] {
     *out = rmat_build(ctx->single(), scale, edge_factor, seed, weight_seed, symmetrize).release();
+    // the generator's sort buffers (16 B per slot: 32 GiB at scale 26) are of no use to the
+    // operators: do not let them fill the frontier block cache
+    hip::block_cache_t::instance().trim();
     return (int)GRX_OK;
   });
 }

@@ -72,7 +72,7 @@ class SingleRunner:
         return self._host
 
     def global_degrees(self):
-        return np.diff(self.host_csr()[0]).astype(np.int64)
+        return np.diff(self.g.offsets_to_host()).astype(np.int64)
 
     def bfs(self, source: int, opts: ea.Options) -> int:
         _, st = ea.bfs(self.ctx, self.g, source, self.depth, opts)
@@ -394,8 +394,8 @@ class PartitionedRunner:
         self.ctx = ctx = ea.Context(ctx.device, stream=self.stream.cuda_stream)
         full = ea.Graph.rmat(ctx, scale, edge_factor, seed, weight_seed, True)
         self.n, self.nnz = full.n_rows, full.nnz
-        self._host = full.to_host() if self.rank == 0 else None
-        ap = full.to_host()[0] if self._host is None else self._host[0]
+        self._host = None    # the CPU baseline leg runs at N = 1 only
+        ap = full.offsets_to_host()
         self._deg = np.diff(ap).astype(np.int64)
         h = ea._VP()
         lo, hi = C.c_int32(), C.c_int32()

@@ -136,7 +136,8 @@ class block_cache_t {
     parked_ = 0;
   }
   static constexpr std::size_t min_bytes = 1ull << 20;
-  static constexpr std::size_t limit_bytes = 32ull << 30;  // 32 GiB of a 288 GB part
+  static constexpr std::size_t limit_bytes = 64ull << 30;  // 64 GiB of a 288 GB part (an RMAT-26
+                                                           // enactor holds 2 x 12.9 GB of frontiers)
 
  private:
   block_cache_t() = default;
