@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the OpenMP CPU baseline must not spin
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver: dmabuf IPC only (RCCL)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 
