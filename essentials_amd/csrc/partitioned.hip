@@ -103,9 +103,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-__global__ void publish_count_kernel(int64_t* send, const unsigned long long* counters) {
-  send[0] = (int64_t)counters[hip::kernels::C_SELECT];
-}
 
 template <typename label_t, bool DEDUPE>
 __global__ void __launch_bounds__(256)
@@ -290,19 +287,18 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
     const int64_t count = (int64_t)fout.get_number_of_elements();
     auto& ws = sc.workspace();
     unsigned long long* counters = ws.counters();
-    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
-                                 sc.stream()));
+    // counters[C_SELECT] is zero here (the advance's hand-off cleared every counter)
     if (count) {
       const unsigned grid = (unsigned)std::min<int64_t>((count + APPEND_TILE - 1) / APPEND_TILE,
                                                         (int64_t)sc.compute_units() * 8);
       pack_pairs_kernel<label_t><<<grid, 256, 0, sc.stream()>>>(d_scratch, count, labels, d_send,
                                                                  send_capacity, counters);
+      GRX_HIP_CHECK(hipGetLastError());
     }
-    publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
-    GRX_HIP_CHECK(hipGetLastError());
-    GRX_HIP_CHECK(hipMemcpyAsync(ws.mirror() + hip::kernels::C_SELECT, counters + hip::kernels::C_SELECT,
-                                 sizeof(unsigned long long), hipMemcpyDeviceToHost, sc.stream()));
-    unsigned long long* m = operators::advance::detail::fetch_counters(sc);  // follows the copy
+    // the hand-off also leaves the pair count in the slot's header word
+    unsigned long long* m = operators::advance::detail::await_counters(
+        sc, operators::advance::detail::publish_counters(sc, reinterpret_cast<long long*>(d_send),
+                                                         hip::kernels::C_SELECT));
     error::throw_if_exception(m[hip::kernels::C_OVERFLOW] != 0,
                               "grx_partitioned_expand: send buffer too small (needs V + 1 words)");
     *n_found = (int64_t)m[hip::kernels::C_SELECT];
@@ -505,8 +501,8 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
     }
     // 1. admit what the other ranks found last superstep -> this superstep's owned frontier
     if (d_recv) {
-      GRX_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), sc.stream()));
-      // the gather carries the finds of superstep round - 1
+      // *count_dev is zero: the previous step's hand-off cleared it.
+      // The gather carries the finds of superstep round - 1
       enqueue_admit(sc, edge_op, recv_format, d_labels, local->n_rows, d_stamp, round - 1, d_recv,
                     world, slot, me, lo, hi, d_frontier, frontier_capacity, count_dev,
                     counters + hip::kernels::C_OVERFLOW);
@@ -543,9 +539,8 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                                                        (unsigned long long)local->nnz, d_scratch,
                                                        (std::size_t)scratch_capacity, sc);
     }
-    // 3. pack the finds (their number is counters[C_OUT], still on the device)
-    GRX_HIP_CHECK(hipMemsetAsync(counters + hip::kernels::C_SELECT, 0, sizeof(unsigned long long),
-                                 sc.stream()));
+    // 3. pack the finds (their number is counters[C_OUT], still on the device; C_SELECT is zero:
+    //    every hand-off clears it)
     const unsigned pgrid = (unsigned)sc.compute_units() * 8;
     if (edge_op == GRX_OP_BFS)
       pack_pairs_kernel<int32_t><<<pgrid, 256, 0, sc.stream()>>>(
@@ -555,10 +550,12 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
       pack_pairs_kernel<float><<<pgrid, 256, 0, sc.stream()>>>(
           d_scratch, 0, (float*)d_labels, d_send, send_capacity, counters,
           counters + hip::kernels::C_OUT);
-    publish_count_kernel<<<1, 1, 0, sc.stream()>>>(d_send, counters);
     GRX_HIP_CHECK(hipGetLastError());
-    // 4. hand the counters over (overflow flag) and clear them -- nobody waits here
-    ctx->pending_sequence = operators::advance::detail::publish_counters(sc);
+    // 4. hand the counters over (overflow flag), write the pair count into the slot's header, clear
+    //    the counters and the frontier length (the next admit accumulates into it) -- one launch,
+    //    nobody waits here
+    ctx->pending_sequence = operators::advance::detail::publish_counters(
+        sc, reinterpret_cast<long long*>(d_send), hip::kernels::C_SELECT, count_dev);
     return (int)GRX_OK;
   });
 }

@@ -62,7 +62,8 @@ inline unsigned grid_for(std::size_t items, std::size_t per_block, unsigned cap 
  */
 template <int header_only = 0>  // a template so that every translation unit may define it
 __global__ void publish_counters_kernel(unsigned long long* counters, unsigned long long* mirror,
-                                        unsigned long long sequence) {
+                                        unsigned long long sequence, long long* copy_to,
+                                        int copy_slot, unsigned long long* zero_this) {
   const int i = threadIdx.x;
 #ifdef GRX_TILE_TIMING
   if (i < 31 && i != 16) {  // diagnostic build: slots 20..28 carry the tile kernel's phase clocks
@@ -71,8 +72,16 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
 #endif
     // the counters were updated by device-scope atomics (memory side); read and clear them
     // with cache-bypassing accesses instead of trusting what this XCD's L2 may still hold
-    mirror[i] = __hip_atomic_exchange(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long value =
+        __hip_atomic_exchange(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mirror[i] = value;
+    // fused pipelines: leave one counter where the next device-side consumer reads it (a send
+    // slot's header) and clear one device word (a frontier length the next admit accumulates)
+    if (copy_to && i == copy_slot)
+      *copy_to = (long long)value;
   }
+  if (zero_this && i == 32)
+    __hip_atomic_store(zero_this, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __threadfence_system();
   __syncthreads();
   if (i == 0) {
@@ -82,10 +91,13 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
 }
 
 /// Enqueue the hand-off (copy to the mirror, clear, stamp); returns the sequence number.
-inline unsigned long long publish_counters(gcuda::standard_context_t& ctx) {
+inline unsigned long long publish_counters(gcuda::standard_context_t& ctx, long long* copy_to = nullptr,
+                                           int copy_slot = 0,
+                                           unsigned long long* zero_this = nullptr) {
   auto& ws = ctx.workspace();
   const unsigned long long seq = ws.next_sequence();
-  publish_counters_kernel<0><<<1, 64, 0, ctx.stream()>>>(ws.counters(), ws.mirror(), seq);
+  publish_counters_kernel<0><<<1, 64, 0, ctx.stream()>>>(ws.counters(), ws.mirror(), seq, copy_to,
+                                                         copy_slot, zero_this);
   GRX_HIP_CHECK(hipGetLastError());
   return seq;
 }

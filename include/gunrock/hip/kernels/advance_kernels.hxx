@@ -64,9 +64,9 @@ enum counter_slot : int {
   C_OVERFLOW = 3,   ///< set when an output write was dropped for lack of capacity
   C_TILE = 4,       ///< dynamic tile cursor (work_stealing)
   C_NEXT_WORK = 5,  ///< sum of degrees of the emitted neighbours (work of the next advance)
+  C_SELECT = 6,     ///< packers (partitioned supersteps): number of selected elements
   C_BUCKET0 = 8,    ///< bucketing: small / medium queue cursors (8, 9)
-  C_MAXDEG = 12,    ///< max degree reduction
-  C_SELECT = 16     ///< compaction: number of selected elements
+  C_MAXDEG = 12     ///< max degree reduction (slots >= 16 are not handed to the host)
 };
 
 template <typename vertex_t, typename edge_t>
