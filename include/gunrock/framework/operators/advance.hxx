@@ -66,9 +66,9 @@ __global__ void publish_counters_kernel(unsigned long long* counters, unsigned l
                                         int copy_slot, unsigned long long* zero_this) {
   const int i = threadIdx.x;
 #ifdef GRX_TILE_TIMING
-  if (i < 31 && i != 16) {  // diagnostic build: slots 20..28 carry the tile kernel's phase clocks
+  if (i < 31) {  // diagnostic build: slots 24..30 carry the tile kernel's phase clocks
 #else
-  if (i < 16) {
+  if (i < 24) {  // 0..15 operator counters, 16..23 tile-pool cursors
 #endif
     // the counters were updated by device-scope atomics (memory side); read and clear them
     // with cache-bypassing accesses instead of trusting what this XCD's L2 may still hold
@@ -213,12 +213,12 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
     std::fprintf(stderr, "[grx] advance done: out %llu chunks %llu next_work %llu\n", m[k::C_OUT],
                  m[k::C_CHUNKS], m[k::C_NEXT_WORK]);
 #ifdef GRX_TILE_TIMING
-  if (std::getenv("GRX_DEBUG") && m[26])
+  if (std::getenv("GRX_DEBUG") && m[30])
     std::fprintf(stderr,
                  "[grx] tile timing (us, mean per workgroup of %llu): stage %.1f edges %.1f drain %.1f "
                  "total %.1f max-total %.1f | tiles/wg %.2f iters/wg %.2f\n",
-                 m[26], m[20] / 100.0 / m[26], m[21] / 100.0 / m[26], m[25] / 100.0 / m[26],
-                 m[24] / 100.0 / m[26], m[28] / 100.0, (double)m[23] / m[26], (double)m[22] / m[26]);
+                 m[30], m[24] / 100.0 / m[30], m[25] / 100.0 / m[30], m[29] / 100.0 / m[30],
+                 m[28] / 100.0 / m[30], m[7] / 100.0, (double)m[27] / m[30], (double)m[26] / m[30]);
 #endif
   error::throw_if_exception(m[k::C_OVERFLOW] != 0,
                             "advance: output frontier capacity exceeded");

@@ -66,7 +66,8 @@ enum counter_slot : int {
   C_NEXT_WORK = 5,  ///< sum of degrees of the emitted neighbours (work of the next advance)
   C_SELECT = 6,     ///< packers (partitioned supersteps): number of selected elements
   C_BUCKET0 = 8,    ///< bucketing: small / medium queue cursors (8, 9)
-  C_MAXDEG = 12     ///< max degree reduction (slots >= 16 are not handed to the host)
+  C_MAXDEG = 12,    ///< max degree reduction
+  C_TILE_POOL = 16  ///< 16..23: dynamic tile cursors, one per pool of workgroups (work_stealing)
 };
 
 template <typename vertex_t, typename edge_t>
@@ -323,10 +324,22 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   // Under load a dependent global access costs a full trip through queues that the expansion's
   // gathers keep deep (~10 us on RMAT-22 level 2), and a tile needs two of them before its first
   // edge: fetched in line they were most of the kernel's time.
+  // Dynamic claims (work_stealing): workgroups form up to 8 pools (blockIdx % 8 -- workgroups are
+  // dealt round-robin to the 8 XCDs), pool p owns tiles p, p + 8, ... and hands them out through
+  // its own cursor: eight cursor addresses instead of one (a single address retires ~90 atomics/us),
+  // and the cursor value a claim returns was REQUESTED during the previous claim, a whole tile
+  // earlier, so its round trip is off the critical path.
+  const unsigned pools = gridDim.x < 8u ? gridDim.x : 8u;
+  const unsigned pool = blockIdx.x % pools;
+  unsigned long long pending = 0;  // thread 0: cursor value requested but not yet handed out
+  if (DYNAMIC && tid == 0)
+    pending = atomicAdd(&counters[C_TILE_POOL + pool], 1ull);
   auto claim = [&](unsigned long long after) -> unsigned long long {
     if (DYNAMIC) {
-      if (tid == 0)
-        s_tile = atomicAdd(&counters[C_TILE], 1ull);
+      if (tid == 0) {
+        s_tile = pending * pools + pool;
+        pending = atomicAdd(&counters[C_TILE_POOL + pool], 1ull);
+      }
       __syncthreads();
       const unsigned long long t = s_tile;
       __syncthreads();  // s_tile is rewritten by the next claim
@@ -477,16 +490,16 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   if constexpr (PACKED)
     drain_block_summing(wq, s_counts, &s_base, output, capacity, counters, degree_of);
 #ifdef GRX_TILE_TIMING
-  if (tid == 0) {  // 100 MHz ticks, summed over workgroups (slots 20..27), max total in 28
+  if (tid == 0) {  // 100 MHz ticks, summed over workgroups (slots 24..30), max total in slot 7
     const unsigned long long tt_end = wall_clock64();
-    atomicAdd(&counters[20], tt_stage);
-    atomicAdd(&counters[21], tt_edges);
-    atomicAdd(&counters[22], tt_iters);
-    atomicAdd(&counters[23], tt_tiles);
-    atomicAdd(&counters[24], tt_end - tt_start);
-    atomicAdd(&counters[25], tt_end - tt_loop_end);
-    atomicAdd(&counters[26], 1ull);
-    atomicMax(&counters[28], tt_end - tt_start);
+    atomicAdd(&counters[24], tt_stage);
+    atomicAdd(&counters[25], tt_edges);
+    atomicAdd(&counters[26], tt_iters);
+    atomicAdd(&counters[27], tt_tiles);
+    atomicAdd(&counters[28], tt_end - tt_start);
+    atomicAdd(&counters[29], tt_end - tt_loop_end);
+    atomicAdd(&counters[30], 1ull);
+    atomicMax(&counters[7], tt_end - tt_start);
   }
 #endif
 }
