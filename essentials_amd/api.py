@@ -179,6 +179,8 @@ _SIGNATURES = {
                                        C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_int32, _VP, C.c_int64, _VP, _VP, C.c_int64,
                                        _VP, C.c_int64]),
+    "grx_pagerank_partitioned_scatter": (C.c_int, [_VP, _VP, C.c_float, _VP, _VP, C.c_int32, _VP,
+                                                   C.c_int32, C.c_int32, C.POINTER(_Options)]),
     "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "grx_measure_gather_rate": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }

@@ -42,3 +42,72 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
     });
   });
 }
+
+/* One PageRank iteration's local half on a vertex-partitioned graph (replicas of p,
+ * every rank scatters from the rows it owns into a private partial vector, the host all-reduces
+ * the partials).  The arithmetic per edge is pr.hxx:140-146's. */
+extern "C" int grx_pagerank_partitioned_scatter(grx_context_t ctx, grx_graph_t local, float alpha,
+                                                const float* d_rank, float* d_scale,
+                                                int32_t compute_scale, float* d_partial,
+                                                int32_t row_begin, int32_t row_end,
+                                                const grx_options* opt) {
+  if (!ctx || !local || !d_rank || !d_scale || !d_partial || row_begin < 0 || row_end < row_begin ||
+      row_end > local->n_rows)
+    return invalid("grx_pagerank_partitioned_scatter: bad arguments");
+  grx_options o;
+  grx_default_options(&o);
+  if (opt)
+    o = *opt;
+  o.holes_layout = 0;
+  return guarded([&] {
+    return with_load_balance(o.load_balance, [&](auto lb_tag) -> int {
+      constexpr auto lb = decltype(lb_tag)::value;
+      auto& sc = ctx->single();
+      scoped_options scope(sc, &o);
+      graph_type G = local->view();
+      const std::size_t n = (std::size_t)local->n_rows;
+      float* scale = d_scale;
+      if (compute_scale) {
+        // alpha / (sum of out-weights) for owned rows with edges; 0 elsewhere (pr.hxx:77-91)
+        hip::for_each_index(
+            n,
+            [G, scale, alpha] __device__(std::size_t i) {
+              float total = 0;
+              const edge_t begin = G.get_starting_edge((vertex_t)i);
+              const edge_t end = begin + G.get_number_of_neighbors((vertex_t)i);
+              for (edge_t e = begin; e < end; ++e)
+                total += G.get_edge_weight(e);
+              scale[i] = total != 0 ? alpha / total : 0.0f;
+            },
+            sc.stream());
+      }
+      // partial[0..V) = 0, partial[V] = alpha * (rank mass of the OWNED dangling vertices)
+      hip::fill(d_partial, n, 0.0f, sc.stream());
+      const std::size_t owned = (std::size_t)(row_end - row_begin);
+      const float* rank = d_rank;
+      const std::size_t lo = (std::size_t)row_begin;
+      const float dangling = hip::transform_reduce(
+          owned,
+          [rank, scale, alpha, lo] __device__(std::size_t i) -> float {
+            return scale[lo + i] == 0 ? alpha * rank[lo + i] : 0.0f;
+          },
+          0.0f, rocprim::plus<float>(), sc);
+      hip::fill(d_partial + n, 1, dangling, sc.stream());
+      float* partial = d_partial;
+      auto spread = [partial, rank, scale] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                               edge_t const& edge,
+                                                               weight_t const& w) -> bool {
+        math::atomic::add(partial + dst, rank[src] * scale[src] * w);
+        return false;
+      };
+      frontier_type none_in, none_out;
+      hip::device_array_t<edge_t> segments;
+      operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::graph,
+                                  operators::advance_io_type_t::none>(G, spread, &none_in, &none_out,
+                                                                      segments, *ctx->mc);
+      sc.synchronize();
+      return (int)GRX_OK;
+    });
+  });
+}

@@ -9,6 +9,7 @@ PartitionedTraversal  the multi-GPU superstep protocol: one proce
                       owner admission.  The local kernels come from a `kernels` object:
                       HipKernels (the C ABI, production) -- tests may pass another object with
                       the same two methods to exercise the protocol on CPU ranks over gloo.
+PartitionedPageRank   PageRank on the same partition: local scatter + all-reduce of the partials.
 PartitionedRunner     bench-side wrapper: R-MAT graph, slicing, repeated traversals.
 
 Exchange format (one int64 slot per rank): word 0 = number of (vertex,label) pairs the rank
@@ -176,6 +177,12 @@ class HipKernels:
             self.ctx._h, depth.data_ptr(), depth.numel(), level, words.data_ptr(), words.numel()),
             "grx_partitioned_level_bitmap")
 
+    def pr_scatter(self, alpha, p, scale, compute_scale, partial, lo, hi) -> None:
+        """grx_pagerank_partitioned_scatter: partial <- this rank's PageRank contributions."""
+        ea._check(self.lib.grx_pagerank_partitioned_scatter(
+            self.ctx._h, self.g._h, alpha, p.data_ptr(), scale.data_ptr(), int(compute_scale),
+            partial.data_ptr(), lo, hi, C.byref(self.opts)), "grx_pagerank_partitioned_scatter")
+
     def step(self, op, labels, stamp, sent, rnd, recv, fmt, world, slot, rank, lo, hi, frontier,
              fcount, scratch, send) -> None:
         """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> advance -> pack."""
@@ -185,6 +192,54 @@ class HipKernels:
             rank, lo, hi, frontier.data_ptr(), frontier.numel(), fcount.data_ptr(),
             scratch.data_ptr(), scratch.numel(), send.data_ptr(), send.numel()),
             "grx_partitioned_step")
+
+
+class PartitionedPageRank:
+    """PageRank on the vertex partition: every rank keeps a replica of p, scatters
+    from the rows it owns into a private partial vector (`kernels.pr_scatter`, production:
+    grx_pagerank_partitioned_scatter), the partials are ALL-REDUCED (SUM; RCCL on `nccl`) and every
+    rank applies the same update, so the replicas stay identical and the stop test
+    (max |p - p_previous| < tol after >= 1 iteration, pr.hxx:155-178) needs no extra collective."""
+
+    def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int, device):
+        import torch
+        self.torch, self.k, self.dist = torch, kernels, dist
+        self.rank, self.world, self.n, self.lo, self.hi = rank, world, n_global, lo, hi
+        f32 = torch.float32
+        self.scale = torch.zeros(n_global, dtype=f32, device=device)
+        self.partial = torch.zeros(n_global + 1, dtype=f32, device=device)
+        self._backend = dist.get_backend() if dist is not None and world > 1 else None
+
+    def _all_reduce(self, t):
+        if self.world == 1:
+            return
+        if self._backend == "nccl" or not t.is_cuda:
+            self.dist.all_reduce(t)
+        else:  # gloo with device tensors (test rigs): stage through the host
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+
+    def run(self, p, alpha: float = 0.85, tol: float = 1e-6, max_iterations: int = 0) -> dict:
+        """p: replica [V] float32, overwritten with the ranks."""
+        torch = self.torch
+        p.fill_(1.0 / self.n)
+        if p.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            self.k.pr_scatter(alpha, p, self.scale, it == 0, self.partial, self.lo, self.hi)
+            self._all_reduce(self.partial)
+            new = self.partial[: self.n] + (1.0 - alpha + self.partial[self.n]) / self.n
+            err = float((new - p).abs().max())
+            p.copy_(new)
+            it += 1
+            if err < tol or (max_iterations and it >= max_iterations):
+                break
+        if p.is_cuda:
+            torch.cuda.synchronize()
+        return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "iterations": it, "last_error": err}
 
 
 class PartitionedTraversal:

@@ -274,6 +274,19 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                          uint64_t* d_frontier_count, int32_t* d_scratch, int64_t scratch_capacity,
                          int64_t* d_send, int64_t send_capacity);
 
+/* PageRank on the same partition (replicas of the rank vector p): one iteration's
+ * local half.  d_partial[V + 1] <- contributions of the rows this rank owns,
+ *   d_partial[dst] += d_rank[src] * d_scale[src] * w   over the local edges   (pr.hxx:140-146)
+ *   d_partial[V]    = alpha * (sum of d_rank over the OWNED vertices without out-edges)
+ * d_scale[V] (alpha / sum of out-weights, 0 for rows without edges; pr.hxx:77-91) is computed when
+ * compute_scale != 0 and reused otherwise.  The host all-reduces d_partial (SUM) and sets
+ *   p[v] = (1 - alpha + partial[V]) / V + partial[v];  done when max |p - p_previous| < tol.
+ * Synchronous. */
+int grx_pagerank_partitioned_scatter(grx_context_t ctx, grx_graph_t local, float alpha,
+                                     const float* d_rank, float* d_scale, int32_t compute_scale,
+                                     float* d_partial, int32_t row_begin, int32_t row_end,
+                                     const grx_options* opt);
+
 /* ---- measurement helpers ------------------------------------------------- */
 /* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:
  * the achievable-HBM roof quoted beside the 8 TB/s vendor peak. Returns GB/s. */

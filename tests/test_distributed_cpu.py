@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from essentials_amd.distributed import (OP_BFS, OP_SSSP, RECV_LEVEL_BITMAP,  # noqa: E402
-                                        PartitionedTraversal, partition_bounds)
+                                        PartitionedPageRank, PartitionedTraversal, partition_bounds)
 
 
 class NumpyKernels:
@@ -63,6 +63,20 @@ class NumpyKernels:
             fcount[0] = self.admit(op, labels, stamp, rnd - 1, recv, fmt, world, slot, rank, lo, hi,
                                    frontier)
         self.expand(op, labels, rnd, frontier, int(fcount[0]), scratch, sent, send)
+
+    def pr_scatter(self, alpha, p, scale, compute_scale, partial, lo, hi):
+        """grx_pagerank_partitioned_scatter on the local rows."""
+        n = len(self.ap) - 1
+        sc, pr, out = scale.numpy(), p.numpy(), partial.numpy()
+        src = np.repeat(np.arange(n), np.diff(self.ap))
+        if compute_scale:
+            tot = np.zeros(n, np.float32)
+            np.add.at(tot, src, self.ax)
+            sc[:] = np.where(tot != 0, np.float32(alpha) / np.where(tot != 0, tot, 1), 0).astype(np.float32)
+        out[:n] = np.bincount(self.aj, weights=(pr[src] * sc[src] * self.ax).astype(np.float64),
+                              minlength=n).astype(np.float32)
+        owned = np.arange(lo, hi)
+        out[n] = np.float32(alpha) * pr[owned][sc[owned] == 0].sum(dtype=np.float64)
 
     def level_bitmap(self, depth, level, words):
         """grx_partitioned_level_bitmap: bit v = (depth[v] == level)."""
@@ -136,6 +150,13 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
             ok = False; why.append(f"stats {s}: {st}")
         if dense_threshold is not None and reached > 8 * dense_threshold and not st["bitmap_supersteps"]:
             ok = False; why.append(f"no bitmap superstep for {s}: {st}")
+    # PageRank on the same partition against the oracle's restatement of pr.hxx
+    p = torch.empty(n, dtype=torch.float32)
+    st = PartitionedPageRank(k, dist, rank, world, n, lo, hi, "cpu").run(p, 0.85, 1e-6)
+    want, it = o.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    if not np.allclose(p.numpy(), want, rtol=2e-4, atol=1e-9) or abs(st["iterations"] - it) > 1:
+        ok = False; why.append(f"pagerank: max rel err {np.max(np.abs(p.numpy() - want) / want):.2e}, "
+                               f"{st['iterations']} vs {it} iterations")
     open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").write(str(why))
     dist.barrier()
     dist.destroy_process_group()

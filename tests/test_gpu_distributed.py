@@ -76,6 +76,26 @@ def test_partitioned_world1_matches_oracle(oracle):
             assert (dist_.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all()
 
 
+def test_partitioned_pagerank_world1_matches_single(oracle):
+    """grx_pagerank_partitioned_scatter + the host update = grx_pagerank (same arithmetic per edge;
+    float atomics make both order-dependent, hence a tolerance) = the oracle's pr.hxx restatement."""
+    import torch
+    import essentials_amd as ea
+    from essentials_amd.distributed import HipKernels, PartitionedPageRank
+    ctx = ea.Context(0)
+    g = ea.Graph.rmat(ctx, 13, 8, 3, 5, False)       # directed: has dangling vertices
+    Ap, Aj, Ax = g.to_host()
+    want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    single, st1 = ea.pagerank(ctx, g, 0.85, 1e-6)
+    p = torch.empty(g.n_rows, dtype=torch.float32, device="cuda")
+    st = PartitionedPageRank(HipKernels(ctx, g), None, 0, 1, g.n_rows, 0, g.n_rows, "cuda:0").run(
+        p, 0.85, 1e-6)
+    assert abs(st["iterations"] - it) <= 1 and abs(st1.iterations - it) <= 1
+    assert np.allclose(p.cpu().numpy(), want, rtol=2e-4, atol=1e-9)
+    assert np.allclose(p.cpu().numpy(), single.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    assert abs(float(p.sum()) - 1.0) < 1e-3
+
+
 def _rank(rank, world, port, scale, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -85,7 +105,8 @@ def _rank(rank, world, port, scale, out_dir):
     import ctypes as C
     import essentials_amd as ea
     from essentials_amd import api
-    from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
+    from essentials_amd.distributed import (HipKernels, PartitionedPageRank, PartitionedTraversal,
+                                            OP_BFS, OP_SSSP)
     from oracle.oracle import Oracle
     o = Oracle()
     torch.cuda.set_device(0)
@@ -121,6 +142,13 @@ def _rank(rank, world, port, scale, out_dir):
             wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
             if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
                 notes.append(f"sssp {s} {lb.name} {small_slot}")
+    # PageRank over the same slices (all-reduce of the partial vectors)
+    p = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+    st = PartitionedPageRank(HipKernels(ctx, local), dist, rank, world, full.n_rows, lo.value,
+                             hi.value, "cuda:0").run(p, 0.85, 1e-6)
+    want, it = o.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    if not np.allclose(p.cpu().numpy(), want, rtol=2e-4, atol=1e-9) or abs(st["iterations"] - it) > 1:
+        notes.append(f"pagerank {st} vs {it} iterations")
     open(os.path.join(out_dir, f"rank{rank}." + ("bad" if notes else "ok")), "w").write(str(notes))
     dist.barrier()
     dist.destroy_process_group()
