@@ -178,7 +178,7 @@ _SIGNATURES = {
     "grx_partitioned_step": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, _VP, _VP,
                                        C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_int32, _VP, C.c_int64, _VP, _VP, C.c_int64,
-                                       _VP, C.c_int64]),
+                                       _VP, C.c_int64, _VP]),
     "grx_pagerank_partitioned_scatter": (C.c_int, [_VP, _VP, C.c_float, _VP, _VP, C.c_int32, _VP,
                                                    C.c_int32, C.c_int32, C.POINTER(_Options)]),
     "grx_measure_copy_bandwidth": (C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),

@@ -230,6 +230,38 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+/// Admission after an all-reduce(MIN) of the label replicas (dense SSSP supersteps): an owned
+/// vertex enters the next frontier when its label is now below the snapshot taken before the
+/// superstep's advance -- whoever lowered it.  One pass over the owned range, exactly once each.
+template <typename label_t>
+__global__ void __launch_bounds__(256)
+    admit_replica_kernel(const label_t* labels, const label_t* snapshot, int32_t lo, int32_t hi,
+                         int32_t* next, unsigned long long next_capacity,
+                         unsigned long long* next_count, unsigned long long* overflow) {
+  __shared__ tile_append_t<int32_t> lds;
+  const int64_t total = (int64_t)hi - lo;
+  const int64_t stride = (int64_t)gridDim.x * APPEND_TILE;
+  const int64_t rounds = (total + stride - 1) / stride;
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t tile = r * stride + (int64_t)blockIdx.x * APPEND_TILE;
+    int32_t admitted[APPEND_ITEMS];
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < APPEND_ITEMS; ++k) {
+      const int64_t t = tile + k * 256 + threadIdx.x;
+      admitted[k] = -1;
+      if (t < total) {
+        const int32_t v = lo + (int32_t)t;
+        if (labels[v] < snapshot[v]) {
+          admitted[k] = v;
+          keep |= 1u << k;
+        }
+      }
+    }
+    append_tile(lds, admitted, keep, next, next_capacity, next_count, overflow);
+  }
+}
+
 inline unsigned bitmap_grid(int64_t n_items, int cus) {
   const int64_t g = (n_items + 255) / 256;
   const int64_t cap = (int64_t)cus * 8;
@@ -399,7 +431,19 @@ void enqueue_admit(gcuda::standard_context_t& sc, int32_t edge_op, int32_t recv_
                    int32_t world, int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* d_next,
                    int64_t next_capacity, unsigned long long* next_count,
                    unsigned long long* overflow) {
-  if (recv_format == GRX_RECV_LEVEL_BITMAP) {
+  if (recv_format == GRX_RECV_REPLICA_MIN) {
+    const int64_t owned = std::max<int64_t>((int64_t)hi - lo, 1);
+    const unsigned grid = (unsigned)std::min<int64_t>((owned + APPEND_TILE - 1) / APPEND_TILE,
+                                                      (int64_t)sc.compute_units() * 8);
+    if (edge_op == GRX_OP_BFS)
+      admit_replica_kernel<int32_t><<<grid, 256, 0, sc.stream()>>>(
+          (const int32_t*)d_labels, reinterpret_cast<const int32_t*>(d_recv), lo, hi, d_next,
+          (unsigned long long)next_capacity, next_count, overflow);
+    else
+      admit_replica_kernel<float><<<grid, 256, 0, sc.stream()>>>(
+          (const float*)d_labels, reinterpret_cast<const float*>(d_recv), lo, hi, d_next,
+          (unsigned long long)next_capacity, next_count, overflow);
+  } else if (recv_format == GRX_RECV_LEVEL_BITMAP) {
     const int64_t n_words = (n_vertices + 63) / 64;
     admit_bitmap_kernel<<<bitmap_grid(n_words, sc.compute_units()), 256, 0, sc.stream()>>>(
         (int32_t*)d_labels, n_vertices, round + 1,
@@ -422,6 +466,8 @@ void enqueue_admit(gcuda::standard_context_t& sc, int32_t edge_op, int32_t recv_
 }
 
 int check_recv(int32_t edge_op, int32_t recv_format, int64_t n_vertices, int64_t slot) {
+  if (recv_format == GRX_RECV_REPLICA_MIN)
+    return GRX_OK;  // d_recv is the label snapshot, one entry per vertex
   if (recv_format != GRX_RECV_PAIRS && recv_format != GRX_RECV_LEVEL_BITMAP)
     return invalid("partitioned: unknown recv_format");
   if (recv_format == GRX_RECV_LEVEL_BITMAP) {
@@ -470,7 +516,8 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                          int32_t round, const int64_t* d_recv, int32_t recv_format, int32_t world,
                          int64_t slot, int32_t me, int32_t lo, int32_t hi, int32_t* d_frontier,
                          int64_t frontier_capacity, uint64_t* d_frontier_count, int32_t* d_scratch,
-                         int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity) {
+                         int64_t scratch_capacity, int64_t* d_send, int64_t send_capacity,
+                         void* d_snapshot) {
   if (!ctx || !local || !d_labels || !d_stamp || !d_sent || !d_frontier || !d_frontier_count ||
       !d_scratch || !d_send || send_capacity < 2 || frontier_capacity < 1 || scratch_capacity < 1 ||
       world < 1 || me < 0 || me >= world)
@@ -507,6 +554,12 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                     world, slot, me, lo, hi, d_frontier, frontier_capacity, count_dev,
                     counters + hip::kernels::C_OVERFLOW);
     }
+    // the labels of the owned range as they stand before this superstep's advance: what a
+    // GRX_RECV_REPLICA_MIN admission of this superstep compares against
+    if (d_snapshot && hi > lo)
+      GRX_HIP_CHECK(hipMemcpyAsync((char*)d_snapshot + (std::size_t)lo * 4,
+                                   (const char*)d_labels + (std::size_t)lo * 4,
+                                   (std::size_t)(hi - lo) * 4, hipMemcpyDeviceToDevice, sc.stream()));
     // 2. local advance over the owned frontier (duplicate-free: work bounded by the rank's edges)
     graph_type G = local->view();
     const std::size_t bound = (std::size_t)std::min<int64_t>(frontier_capacity,

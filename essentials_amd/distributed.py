@@ -30,7 +30,7 @@ from . import api as ea
 
 HBM_PEAK_GBPS = 8000.0
 OP_BFS, OP_SSSP = int(ea.EdgeOp.bfs), int(ea.EdgeOp.sssp)
-RECV_PAIRS, RECV_LEVEL_BITMAP = 0, 1   # grx_recv_format
+RECV_PAIRS, RECV_LEVEL_BITMAP, RECV_REPLICA_MIN = 0, 1, 2   # grx_recv_format
 
 
 def bfs_algorithmic_bytes(edges_traversed: int, vertices_reached: int) -> int:
@@ -184,14 +184,15 @@ class HipKernels:
             partial.data_ptr(), lo, hi, C.byref(self.opts)), "grx_pagerank_partitioned_scatter")
 
     def step(self, op, labels, stamp, sent, rnd, recv, fmt, world, slot, rank, lo, hi, frontier,
-             fcount, scratch, send) -> None:
-        """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> advance -> pack."""
+             fcount, scratch, send, snapshot=None) -> None:
+        """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> [snapshot the owned
+        labels ->] advance -> pack."""
         ea._check(self.lib.grx_partitioned_step(
             self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), stamp.data_ptr(),
             sent.data_ptr(), rnd, recv.data_ptr() if recv is not None else None, fmt, world, slot,
             rank, lo, hi, frontier.data_ptr(), frontier.numel(), fcount.data_ptr(),
-            scratch.data_ptr(), scratch.numel(), send.data_ptr(), send.numel()),
-            "grx_partitioned_step")
+            scratch.data_ptr(), scratch.numel(), send.data_ptr(), send.numel(),
+            snapshot.data_ptr() if snapshot is not None else None), "grx_partitioned_step")
 
 
 class PartitionedPageRank:
@@ -249,7 +250,8 @@ class PartitionedTraversal:
 
     def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int,
                  local_nnz: int, device, small_slot: int | None = None, fused: bool = True,
-                 stream=None, dense_threshold: int | None = None):
+                 stream=None, dense_threshold: int | None = None,
+                 replica_threshold: int | None = None):
         """fused=True uses kernels.step (one enqueue-only call + one host synchronisation per
         superstep); it needs the engine context and the collectives on ONE stream: pass that
         torch stream as `stream` (the context must have been created on stream.cuda_stream)."""
@@ -280,6 +282,11 @@ class PartitionedTraversal:
         self.dense_threshold = int(dense_threshold if dense_threshold is not None
                                    else max(n_global // 64, self.slot0 - 1))
         self.can_dense = hasattr(kernels, "level_bitmap")
+        # dense SSSP supersteps all-reduce (MIN) the distance replicas instead of gathering pairs:
+        # 2 x 4 V bytes through the ring against world x 8 bytes per find of the busiest rank
+        self.replica_threshold = int(replica_threshold if replica_threshold is not None
+                                     else max(n_global // max(world, 1), self.slot0 - 1))
+        self.snapshot = torch.zeros(n_global, dtype=torch.float32, device=device)
         self.bits = torch.zeros(self.words, dtype=i64, device=device)
         self.recv_bits = torch.zeros(world * self.words, dtype=i64, device=device)
         self._backend = dist.get_backend() if dist is not None and world > 1 else None
@@ -297,6 +304,17 @@ class PartitionedTraversal:
             parts = [self.torch.empty_like(h) for _ in range(self.world)]
             self.dist.all_gather(parts, h)
             recv.copy_(self.torch.cat(parts).to(recv.device))
+
+    def _all_reduce_min(self, labels):
+        if self.world == 1:
+            return
+        op = self.dist.ReduceOp.MIN
+        if self._backend == "nccl" or not labels.is_cuda:
+            self.dist.all_reduce(labels, op=op)
+        else:  # gloo with device tensors (test rigs): stage through the host
+            h = labels.cpu()
+            self.dist.all_reduce(h, op=op)
+            labels.copy_(h)
 
     def run(self, op: int, source: int, labels) -> dict:
         """labels: replica [V] (int32 for BFS, float32 for SSSP), overwritten."""
@@ -320,12 +338,13 @@ class PartitionedTraversal:
         if labels.is_cuda:
             torch.cuda.current_stream().synchronize()
         t0 = time.perf_counter()
-        rounds = found_total = collectives = dense = 0
+        rounds = found_total = collectives = dense = reduced = 0
         recv_prev, slot_prev, fmt_prev = None, 0, RECV_PAIRS
+        snapshot = self.snapshot if op == OP_SSSP else None
         while True:
             self.k.step(op, labels, self.stamp, self.sent, rounds, recv_prev, fmt_prev, self.world,
                         slot_prev, self.rank, self.lo, self.hi, frontier, self.fcount, self.scratch,
-                        self.send)
+                        self.send, snapshot)
             slot, fmt = self.slot0, RECV_PAIRS
             recv = self.recv
             self._all_gather(recv, self.send[:slot])
@@ -342,6 +361,13 @@ class PartitionedTraversal:
                 self._all_gather(recv, self.bits)      # same stream: ordered after the bitmap kernel
                 collectives += 1
                 dense += 1
+            elif op == OP_SSSP and most > self.replica_threshold:
+                # the replicas already hold every rank's own improvements: combine them in place;
+                # the next step admits what fell below its snapshot
+                self._all_reduce_min(labels)
+                recv, slot, fmt = self.snapshot, 0, RECV_REPLICA_MIN
+                collectives += 1
+                reduced += 1
             elif most > slot - 1:
                 slot = min(((most + 1 + 4095) // 4096) * 4096, self.send.numel())
                 if self._recv_big is None or self._recv_big.numel() < self.world * slot:
@@ -357,7 +383,7 @@ class PartitionedTraversal:
             torch.cuda.current_stream().synchronize()
         return {"elapsed_ms": (time.perf_counter() - t0) * 1e3, "supersteps": rounds + 1,
                 "pairs_exchanged": found_total, "collectives": collectives, "fused": True,
-                "bitmap_supersteps": dense}
+                "bitmap_supersteps": dense, "allreduce_supersteps": reduced}
 
     def _run(self, op: int, source: int, labels) -> dict:
         torch = self.torch

@@ -236,8 +236,12 @@ int grx_partitioned_expand(grx_context_t ctx, grx_graph_t local, const grx_optio
 /* What a gathered buffer holds. */
 typedef enum grx_recv_format {
   GRX_RECV_PAIRS = 0,        /* per rank: [count | (vertex,label) ...], `slot` words each           */
-  GRX_RECV_LEVEL_BITMAP = 1  /* BFS only, dense supersteps: per rank ceil(V/64) words, bit v = "this
+  GRX_RECV_LEVEL_BITMAP = 1, /* BFS only, dense supersteps: per rank ceil(V/64) words, bit v = "this
                                 rank discovered v in the superstep"; labels are implied (the level) */
+  GRX_RECV_REPLICA_MIN = 2   /* dense SSSP supersteps: nothing was gathered -- the host all-reduced
+                                (MIN) the label replicas in place; d_recv is the label SNAPSHOT
+                                (one entry per vertex) grx_partitioned_step took before the advance:
+                                owned vertices whose label fell below it are admitted             */
 } grx_recv_format;
 
 /* Dense BFS exchange, enqueue-only: d_words[ceil(V/64)] <- bit v = (d_depth[v] == level).  Called
@@ -265,14 +269,15 @@ int grx_partitioned_admit(grx_context_t ctx, int32_t edge_op, void* d_labels, in
  * caller issues the collective on the SAME stream (create the context on that stream) and
  * synchronises once per superstep, on the gathered counts.  d_recv == NULL on the first superstep
  * (the caller preset d_frontier / *d_frontier_count).  Buffer overflows of a step are reported by
- * the next call. */
+ * the next call.  d_snapshot (optional, 4 bytes per vertex): receives the labels of the owned range
+ * as they are before the advance, for a GRX_RECV_REPLICA_MIN admission by the next call. */
 int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options* opt,
                          int32_t edge_op, void* d_labels, int32_t* d_stamp, int32_t* d_sent_stamp,
                          int32_t round, const int64_t* d_recv, int32_t recv_format,
                          int32_t world_size, int64_t slot, int32_t my_rank, int32_t row_begin,
                          int32_t row_end, int32_t* d_frontier, int64_t frontier_capacity,
                          uint64_t* d_frontier_count, int32_t* d_scratch, int64_t scratch_capacity,
-                         int64_t* d_send, int64_t send_capacity);
+                         int64_t* d_send, int64_t send_capacity, void* d_snapshot);
 
 /* PageRank on the same partition (replicas of the rank vector p): one iteration's
  * local half.  d_partial[V + 1] <- contributions of the rows this rank owns,

@@ -20,7 +20,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from essentials_amd.distributed import (OP_BFS, OP_SSSP, RECV_LEVEL_BITMAP,  # noqa: E402
+from essentials_amd.distributed import (OP_BFS, OP_SSSP, RECV_LEVEL_BITMAP, RECV_REPLICA_MIN,  # noqa: E402
                                         PartitionedPageRank, PartitionedTraversal, partition_bounds)
 
 
@@ -57,11 +57,13 @@ class NumpyKernels:
         return len(found)
 
     def step(self, op, labels, stamp, sent, rnd, recv, fmt, world, slot, rank, lo, hi, frontier,
-             fcount, scratch, send):
-        """grx_partitioned_step: admit the gather of superstep rnd - 1, advance, pack."""
+             fcount, scratch, send, snapshot=None):
+        """grx_partitioned_step: admit the gather of superstep rnd - 1, snapshot, advance, pack."""
         if recv is not None:
             fcount[0] = self.admit(op, labels, stamp, rnd - 1, recv, fmt, world, slot, rank, lo, hi,
                                    frontier)
+        if snapshot is not None:
+            snapshot.numpy()[lo:hi] = labels.numpy()[lo:hi]
         self.expand(op, labels, rnd, frontier, int(fcount[0]), scratch, sent, send)
 
     def pr_scatter(self, alpha, p, scale, compute_scale, partial, lo, hi):
@@ -87,6 +89,10 @@ class NumpyKernels:
 
     def admit(self, op, labels, stamp, rnd, recv, fmt, world, slot, rank, lo, hi, nxt):
         lab, st, out = labels.numpy(), stamp.numpy(), nxt.numpy()
+        if fmt == RECV_REPLICA_MIN:       # recv = the snapshot; labels were all-reduced (MIN)
+            mine = np.nonzero(lab[lo:hi] < recv.numpy()[lo:hi])[0] + lo
+            out[:len(mine)] = mine
+            return len(mine)
         if fmt == RECV_LEVEL_BITMAP:
             assert op == OP_BFS
             r = recv.numpy().reshape(world, slot)
@@ -120,7 +126,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir, fused=True,
-            dense_threshold=None):
+            dense_threshold=None, replica_threshold=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -131,7 +137,8 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
     lo, hi = b[rank], b[rank + 1]
     k = NumpyKernels(Ap, np.ascontiguousarray(Aj), np.ascontiguousarray(Ax), lo, hi)
     trav = PartitionedTraversal(k, dist, rank, world, n, lo, hi, int(Ap[hi] - Ap[lo]), "cpu",
-                                small_slot=small_slot, fused=fused, dense_threshold=dense_threshold)
+                                small_slot=small_slot, fused=fused, dense_threshold=dense_threshold,
+                                replica_threshold=replica_threshold)
     ok = True
     why = []
     for s in sources:
@@ -141,7 +148,10 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
         if not (depth.numpy() == want).all():
             ok = False; why.append(f"bfs {s}: {int((depth.numpy() != want).sum())} wrong")
         distance = torch.empty(n, dtype=torch.float32)
-        trav.run(OP_SSSP, s, distance)
+        st2 = trav.run(OP_SSSP, s, distance)
+        if (replica_threshold is not None and fused and int((want != 2**31 - 1).sum()) > 8 * replica_threshold
+                and not st2.get("allreduce_supersteps")):
+            ok = False; why.append(f"no all-reduce superstep for {s}: {st2}")
         wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
         if not (distance.numpy().view(np.uint32) == wantw.view(np.uint32)).all():
             ok = False; why.append(f"sssp {s} wrong")
@@ -166,11 +176,23 @@ def _worker(rank, world, port, scale, seed, wseed, sources, small_slot, out_dir,
                                                           (3, 64, True, None), (2, 8, False, None),
                                                           (2, 8, True, 4), (3, 8, False, 4)])
 def test_partitioned_traversal_gloo(tmp_path, world, small_slot, fused, dense):
+    _spawn(tmp_path, world, small_slot, fused, dense, None)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_sssp_allreduce_supersteps_gloo(tmp_path, world):
+    """Supersteps with more than 4 finds on some rank combine the distance replicas with an
+    all-reduce (MIN) and admit against the pre-advance snapshot (GRX_RECV_REPLICA_MIN)."""
+    _spawn(tmp_path, world, 8, True, 4, 4)
+
+
+def _spawn(tmp_path, world, small_slot, fused, dense, replica):
     """small_slot 8 / 64 forces the second (big-slot) all-gather on the wide levels; fused=True is
     the one-call-per-superstep loop bench.py uses, False the two-call (expand / admit) loop;
     dense=4 makes BFS supersteps with more than 4 finds exchange level bitmaps."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path), fused, dense),
+    mp.spawn(_worker, args=(world, port, 9, 4, 7, [0, 5, 300], small_slot, str(tmp_path), fused, dense,
+                            replica),
              nprocs=world, join=True)
     names = sorted(os.listdir(tmp_path))
     notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}

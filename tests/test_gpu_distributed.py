@@ -62,7 +62,7 @@ def test_partitioned_world1_matches_oracle(oracle):
                                      (16, True, 8), (16, False, 8)):
         trav = PartitionedTraversal(HipKernels(ctx, g), None, 0, 1, g.n_rows, 0, g.n_rows, g.nnz,
                                     "cuda:0", small_slot=small_slot, fused=fused, stream=stream,
-                                    dense_threshold=dense)
+                                    dense_threshold=dense, replica_threshold=dense)
         assert trav.fused == fused
         for s in (0, 7217):
             depth = torch.empty(g.n_rows, dtype=torch.int32, device="cuda")
@@ -71,9 +71,11 @@ def test_partitioned_world1_matches_oracle(oracle):
             assert (depth.cpu().numpy() == want).all(), (small_slot, fused, dense, s)
             assert (st["bitmap_supersteps"] > 0) == (dense == 8), st
             dist_ = torch.empty(g.n_rows, dtype=torch.float32, device="cuda")
-            trav.run(OP_SSSP, s, dist_)
+            st2 = trav.run(OP_SSSP, s, dist_)
             wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, s)
             assert (dist_.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all()
+            if fused:
+                assert (st2["allreduce_supersteps"] > 0) == (dense == 8), st2
 
 
 def test_partitioned_pagerank_world1_matches_single(oracle):
@@ -119,18 +121,19 @@ def _rank(rank, world, port, scale, out_dir):
                                                       C.byref(hi)), "partition")
     local = ea.Graph(h)
     notes = []
-    for lb, small_slot, dense in ((ea.LoadBalance.block_mapped, None, None),
-                                  (ea.LoadBalance.block_mapped, 64, 1 << 30),
-                                  (ea.LoadBalance.block_mapped, 64, 32),
-                                  (ea.LoadBalance.merge_path, None, None),
-                                  (ea.LoadBalance.merge_path, 64, 1 << 30),
-                                  (ea.LoadBalance.merge_path, 64, 32)):
+    for lb, small_slot, dense, replica in ((ea.LoadBalance.block_mapped, None, None, None),
+                                           (ea.LoadBalance.block_mapped, 64, 1 << 30, 1 << 30),
+                                           (ea.LoadBalance.block_mapped, 64, 32, 32),
+                                           (ea.LoadBalance.merge_path, None, None, None),
+                                           (ea.LoadBalance.merge_path, 64, 1 << 30, None),
+                                           (ea.LoadBalance.merge_path, 64, 32, None)):
         # block_mapped: the fused one-call superstep; merge_path: the two-call loop;
-        # dense 32: BFS supersteps with more finds exchange level bitmaps
+        # dense 32: BFS supersteps with more finds exchange level bitmaps; replica 32: SSSP
+        # supersteps with more finds all-reduce (MIN) the distance replicas (fused loop only)
         trav = PartitionedTraversal(HipKernels(ctx, local, ea.Options(load_balance=lb)), dist, rank,
                                     world, full.n_rows, lo.value, hi.value, local.nnz, "cuda:0",
                                     small_slot=small_slot, fused=(lb == ea.LoadBalance.block_mapped),
-                                    stream=stream, dense_threshold=dense)
+                                    stream=stream, dense_threshold=dense, replica_threshold=replica)
         for s in (0, 1830):
             depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
             trav.run(OP_BFS, s, depth)
@@ -138,10 +141,12 @@ def _rank(rank, world, port, scale, out_dir):
             if not (depth.cpu().numpy() == want).all():
                 notes.append(f"bfs {s} {lb.name} {small_slot} {dense}")
             d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
-            trav.run(OP_SSSP, s, d)
+            st2 = trav.run(OP_SSSP, s, d)
             wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
             if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
-                notes.append(f"sssp {s} {lb.name} {small_slot}")
+                notes.append(f"sssp {s} {lb.name} {small_slot} {replica}")
+            if replica == 32 and not st2.get("allreduce_supersteps"):
+                notes.append(f"sssp {s}: no all-reduce superstep {st2}")
     # PageRank over the same slices (all-reduce of the partial vectors)
     p = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
     st = PartitionedPageRank(HipKernels(ctx, local), dist, rank, world, full.n_rows, lo.value,
