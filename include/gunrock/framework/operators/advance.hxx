@@ -227,17 +227,19 @@ void finish_output(frontier_t& output, bool holes, unsigned long long total,
     output.set_work_hint(m[k::C_NEXT_WORK]);
 }
 
-/// Input slots per tile of the block_mapped kernel.
+/// Input slots per tile of the block_mapped kernel: 256.  Narrower tiles were measured slower on
+/// wide levels (more partially filled 1024-edge steps) AND on narrow ones (a 163 K-vertex level at
+/// 64 slots: BFS 1.47 vs 1.39 ms) -- DESIGN.md section 5; options().tile_width is an experiment knob.
 inline unsigned tile_width_for(std::size_t n_in, unsigned persistent_workgroups,
                                gcuda::standard_context_t& ctx) {
-  unsigned w = ctx.options().tile_width;
-  if (w == 0)
-    w = (unsigned)k::ADV_BLOCK;
-  unsigned p = 16;
-  while (p * 2 <= w && p * 2 <= (unsigned)k::ADV_BLOCK)
-    p *= 2;
   (void)n_in;
   (void)persistent_workgroups;
+  unsigned w = ctx.options().tile_width;
+  if (w == 0)
+    return (unsigned)k::ADV_BLOCK;
+  unsigned p = 16;  // round down to a power of two in [16, 256]
+  while (p * 2 <= w && p * 2 <= (unsigned)k::ADV_BLOCK)
+    p *= 2;
   return p;
 }
 
