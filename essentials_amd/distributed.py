@@ -85,6 +85,9 @@ class SingleRunner:
         self.last["sssp"] = st
         return st.edges_traversed
 
+    def flush_edges(self) -> int:
+        return 0   # bfs() / sssp() already returned their counts
+
     def bfs_roofline(self, source: int, lb) -> dict:
         """Kernel-level roofline of one BFS: HIP events around every advance launch."""
         best = None
@@ -495,7 +498,10 @@ class PartitionedRunner:
             self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist, self.rank,
                                              self.world, self.n, self.lo, self.hi, self.local.nnz,
                                              dev, fused=fused, stream=self.stream)
+        self._torch = torch
         self._deg_dev = torch.from_numpy(self._deg).to(dev)
+        self._zero = torch.zeros((), dtype=torch.int64, device=dev)
+        self._acc = self._zero.clone()
         self.last = {}
 
     def host_csr(self):
@@ -505,19 +511,36 @@ class PartitionedRunner:
         return self._deg
 
     def _edges(self, labels, unreached):
-        return int(self._deg_dev[labels != unreached].sum().item())
+        """Sum of the out-degrees of the reached vertices, as a device scalar (same stream as the
+        traversal: ordered after it and before the next one overwrites the labels)."""
+        torch = self._torch
+        with torch.cuda.stream(self.stream):
+            e = torch.where(labels != unreached, self._deg_dev, self._zero).sum()
+            self._acc = self._acc + e
+            return e
 
     def bfs(self, source: int, opts=None) -> int:
+        """Returns 0: the traversed-edge count accumulates on the device (no host read in the timed
+        region); flush_edges() hands the total over."""
         self.last["bfs"] = self.trav.run(OP_BFS, source, self.depth)
-        return self._edges(self.depth, ea.INT_UNREACHED)
+        self._edges(self.depth, ea.INT_UNREACHED)
+        return 0
 
     def sssp(self, source: int, opts=None) -> int:
         self.last["sssp"] = self.trav.run(OP_SSSP, source, self.distance)
-        return self._edges(self.distance, ea.FLT_UNREACHED)
+        self._edges(self.distance, ea.FLT_UNREACHED)
+        return 0
+
+    def flush_edges(self) -> int:
+        self.stream.synchronize()
+        total = int(self._acc.item())
+        self._acc = self._zero.clone()
+        return total
 
     def bfs_roofline(self, source: int, lb) -> dict:
         st = self.trav.run(OP_BFS, source, self.depth)
-        edges = self._edges(self.depth, ea.INT_UNREACHED)
+        edges = int(self._edges(self.depth, ea.INT_UNREACHED).item())
+        self.flush_edges()
         reached = int((self.depth != ea.INT_UNREACHED).sum().item())
         nbytes = bfs_algorithmic_bytes(edges, reached)
         achieved = nbytes / (st["elapsed_ms"] * 1e-3) / 1e9
