@@ -62,7 +62,7 @@ enum counter_slot : int {
   C_CHUNKS = 1,     ///< hub chunk queue cursor
   C_WORK = 2,       ///< degree sum / total work of the input frontier
   C_OVERFLOW = 3,   ///< set when an output write was dropped for lack of capacity
-  C_TILE = 4,       ///< dynamic tile cursor (work_stealing)
+  // 4: free
   C_NEXT_WORK = 5,  ///< sum of degrees of the emitted neighbours (work of the next advance)
   C_SELECT = 6,     ///< packers (partitioned supersteps): number of selected elements
   C_BUCKET0 = 8,    ///< bucketing: small / medium queue cursors (8, 9)

@@ -1,5 +1,7 @@
+"""Per-iteration work of the SSSP client (run with GRX_DEBUG=1: each advance prints its output size
+and the degree sum of what it emitted = the edges the next iteration relaxes)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, essentials_amd as ea
 ctx = ea.Context(0)
 g = ea.Graph.rmat(ctx, 22, 16, 1, 7)
