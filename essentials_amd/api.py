@@ -78,7 +78,7 @@ class _Stats(C.Structure):
                 ("iterations", C.c_int32), ("advance_launches", C.c_int32),
                 ("vertices_reached", C.c_int64), ("edges_traversed", C.c_int64),
                 ("levels_recorded", C.c_int32), ("pull_iterations", C.c_int32),
-                ("frontier_slots", C.c_int64 * 64)]
+                ("frontier_slots", C.c_int64 * 64), ("edges_expanded", C.c_int64)]
 
 
 @dataclass
@@ -121,12 +121,14 @@ class Stats:
     edges_traversed: int = 0
     frontier_slots: list = field(default_factory=list)
     pull_iterations: int = 0
+    edges_expanded: int = 0
 
     @staticmethod
     def _from(s: _Stats) -> "Stats":
         return Stats(s.elapsed_ms, s.advance_kernel_ms, s.iterations, s.advance_launches,
                      s.vertices_reached, s.edges_traversed,
-                     list(s.frontier_slots[: s.levels_recorded]), s.pull_iterations)
+                     list(s.frontier_slots[: s.levels_recorded]), s.pull_iterations,
+                     s.edges_expanded)
 
 
 # symbol -> (restype, argtypes); the list is also what tests check against the header

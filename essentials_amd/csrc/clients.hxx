@@ -30,9 +30,13 @@ struct level_log_t {
   static constexpr int max_levels = 64;
   int levels = 0;
   long long input_slots[max_levels] = {0};
-  void note(std::size_t slots) {
+  long long edges_expanded = 0;   // sum of the input frontiers' work hints (exact when an advance
+                                  // produced the frontier; the source's own degree is added by the caller)
+  void note(std::size_t slots, unsigned long long work = ~0ull) {
     if (levels < max_levels)
       input_slots[levels] = (long long)slots;
+    if (work != ~0ull)
+      edges_expanded += (long long)work;
     ++levels;
   }
 };
@@ -92,7 +96,8 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     auto E = this->get_enactor();
     auto P = this->get_problem();
     auto G = P->get_graph();
-    P->log.note(E->get_input_frontier()->get_number_of_elements());
+    P->log.note(E->get_input_frontier()->get_number_of_elements(),
+                E->get_input_frontier()->work_hint());
 
     vertex_t* depth = P->depth;
     const vertex_t next_level = this->iteration + 1;
@@ -290,7 +295,8 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
     auto E = this->get_enactor();
     auto P = this->get_problem();
     auto G = P->get_graph();
-    P->log.note(E->get_input_frontier()->get_number_of_elements());
+    P->log.note(E->get_input_frontier()->get_number_of_elements(),
+                E->get_input_frontier()->work_hint());
 
     weight_t* distance = P->distance;
     int* stamp = P->stamp.data();

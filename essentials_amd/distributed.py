@@ -144,6 +144,8 @@ class SingleRunner:
             d[k] = {"enact_ms": st.elapsed_ms, "iterations": st.iterations,
                     "edges_traversed": st.edges_traversed, "vertices_reached": st.vertices_reached,
                     "mteps_enact": st.edges_traversed / max(st.elapsed_ms, 1e-9) / 1e3,
+                    "edges_expanded": st.edges_expanded,
+                    "mteps_expanded": st.edges_expanded / max(st.elapsed_ms, 1e-9) / 1e3,
                     "frontier_slots": st.frontier_slots[:16]}
         return d
 

@@ -117,6 +117,9 @@ typedef struct grx_stats {
   int32_t levels_recorded;     /* min(iterations, 64)                                  */
   int32_t pull_iterations;     /* direction-optimised BFS: levels expanded by pulling   */
   int64_t frontier_slots[64];  /* input-frontier length of each iteration              */
+  int64_t edges_expanded;      /* BFS/SSSP push: functor calls = sum over iterations of the input
+                                  frontier's degrees (SSSP relaxes a vertex again whenever its
+                                  distance improved: > edges_traversed)                   */
 } grx_stats;
 
 /* ---- library ------------------------------------------------------------- */

@@ -41,7 +41,7 @@ def test_python_binding_covers_the_header():
 def test_struct_layouts_match_header():
     from essentials_amd.api import _Options, _Stats
     assert C.sizeof(_Options) == 12 * 4         # 12 x int32/float
-    assert C.sizeof(_Stats) == 4 * 4 + 2 * 8 + 2 * 4 + 64 * 8
+    assert C.sizeof(_Stats) == 4 * 4 + 2 * 8 + 2 * 4 + 64 * 8 + 8
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -96,6 +96,8 @@ def test_bfs_golden(ea, ctx, oracle, golden, lb):
             assert sha(d) == run["bfs_sha256"], (name, run["source"], lb)
             assert st.vertices_reached == run["reached"]
             assert st.edges_traversed == run["edges_traversed"]
+            # a push BFS expands every reached vertex exactly once
+            assert st.edges_expanded == st.edges_traversed, (name, lb, st)
             # packed frontiers: one loop() per BFS level plus the empty-output one
             assert st.iterations == run["max_depth"] + 1, (name, lb, st)
 
@@ -136,6 +138,8 @@ def test_sssp_golden_bit_exact(ea, ctx, oracle, golden, lb):
         for run in g["runs"]:
             d, st = ea.sssp(ctx, G, run["source"], options=ea.Options(load_balance=ea.LoadBalance[lb]))
             assert sha(host(d).view(np.uint32)) == run["sssp_bits_sha256"], (name, run["source"], lb)
+            # every reached vertex is expanded at least once; re-expanded when its distance improved
+            assert st.edges_expanded >= st.edges_traversed == run["edges_traversed"], (name, lb, st)
 
 
 def test_sssp_holes_layout(ea, ctx, oracle, golden):
