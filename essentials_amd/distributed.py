@@ -8,7 +8,7 @@ PartitionedTraversal  the multi-GPU superstep protocol: one proce
                       (torch.distributed: backend "nccl" is RCCL over xGMI), min-combine +
                       owner admission.  The local kernels come from a `kernels` object:
                       HipKernels (the C ABI, production) -- tests may pass another object with
-                      the same two methods to exercise the protocol on CPU ranks over gloo.
+                      the same methods to exercise the protocol on CPU ranks over gloo.
 PartitionedPageRank   PageRank on the same partition: local scatter + all-reduce of the partials.
 PartitionedRunner     bench-side wrapper: R-MAT graph, slicing, repeated traversals.
 
@@ -17,6 +17,9 @@ found this superstep, words 1.. = pairs (low 32 bits vertex id, high 32 bits lab
 A first all-gather moves a SMALL fixed slot (header + the first pairs); only when some rank found
 more than fits is a second all-gather issued with a slot sized by the largest count, which every
 rank knows from the first -- so most supersteps cost one collective and no count exchange.
+Dense supersteps use a smaller message instead of the big pair slot: BFS all-gathers per-rank LEVEL
+BITMAPS (V/8 bytes, labels implied), SSSP ALL-REDUCES (MIN) the distance replicas in place and the
+next step admits what fell below its pre-advance snapshot (grx_recv_format in essentials_amd.h).
 """
 from __future__ import annotations
 
