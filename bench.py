@@ -200,7 +200,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "int32 ids / f32 weights",
+        "dtype": "int32/f32",
         "data": "synthetic",
         "config": {"workload": f"BFS+SSSP on RMAT scale-{a.scale} edgefactor-{a.edge_factor} "
                                f"(symmetrized, {runner.nnz} directed edges), {a.lb} advance, "
