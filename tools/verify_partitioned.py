@@ -43,7 +43,8 @@ for s in sources:
     bad += (not ok_d) + (not ok_w)
     print(f"[rank {rank}/{world}] scale {scale} source {s}: bfs {'OK' if ok_d else 'MISMATCH'} "
           f"({st['supersteps']} supersteps, {st['bitmap_supersteps']} bitmap), "
-          f"sssp {'OK' if ok_w else 'MISMATCH'} ({st2['supersteps']} supersteps); rows {lo.value}..{hi.value}",
+          f"sssp {'OK' if ok_w else 'MISMATCH'} ({st2['supersteps']} supersteps, "
+          f"{st2.get('allreduce_supersteps', 0)} all-reduce); rows {lo.value}..{hi.value}",
           flush=True)
 t = torch.tensor([bad])
 dist.all_reduce(t)
