@@ -22,21 +22,35 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, alpha, tol, d_p, ctx->mc);
+      problem.pull = o.direction_optimized != 0;
+      error::throw_if_exception(problem.pull && !G.can_pull(),
+                                "grx_pagerank: the pull form needs in-edges (grx_graph_build_in_edges)");
       problem.init();
       problem.reset();
       enactor_properties_t props;
       props.self_manage_frontiers = true;
-      enactor_type enactor(&problem, ctx->mc, props);
-      enactor.max_iterations = o.max_iterations;
-      const float ms = enactor.enact();
+      float ms = 0;
+      int iterations = 0;
+      if (problem.pull) {
+        clients::pr_pull_enactor_t<problem_type> enactor(&problem, ctx->mc, props);
+        enactor.max_iterations = o.max_iterations;
+        ms = enactor.enact();
+        iterations = enactor.iteration;
+      } else {
+        enactor_type enactor(&problem, ctx->mc, props);
+        enactor.max_iterations = o.max_iterations;
+        ms = enactor.enact();
+        iterations = enactor.iteration;
+      }
       if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->elapsed_ms = ms;
-        stats->iterations = enactor.iteration;
+        stats->iterations = iterations;
         stats->advance_kernel_ms = ctx->single().kernel_clock().total_ms;
         stats->advance_launches = ctx->single().kernel_clock().launches;
         stats->vertices_reached = g->n_rows;
-        stats->edges_traversed = (int64_t)g->nnz * enactor.iteration;
+        stats->edges_traversed = (int64_t)g->nnz * iterations;
+        stats->pull_iterations = problem.pull ? iterations : 0;
       }
       return (int)GRX_OK;
     });

@@ -16,6 +16,8 @@
  */
 #pragma once
 
+#include <gunrock/hip/kernels/reduce_kernels.hxx>
+
 #include <gunrock/framework/framework.hxx>
 #include <gunrock/hip/algorithms.hxx>
 
@@ -332,15 +334,43 @@ struct pr_problem_t : gunrock::problem_t<graph_t> {
   weight_t* rank;  // device, |V|, caller-owned
   hip::device_array_t<weight_t> previous;
   hip::device_array_t<weight_t> out_scale;  // alpha / (sum of out-weights), 0 for dangling
+  // pull formulation (pr_pull_enactor_t): what every vertex hands to each out-neighbour this
+  // iteration, and the in-edge lists of >= RED_HUB edges cut into chunks (once per problem)
+  bool pull = false;
+  hip::device_array_t<weight_t> contribution;
+  using hub_chunk_t = hip::kernels::row_chunk_t<vertex_t, edge_t>;
+  hip::device_array_t<hub_chunk_t> hub_chunks;
 
   pr_problem_t(graph_t& G, weight_t _alpha, weight_t _tol, weight_t* _rank,
                std::shared_ptr<gcuda::multi_context_t> ctx)
       : gunrock::problem_t<graph_t>(G, ctx), alpha(_alpha), tol(_tol), rank(_rank) {}
 
   void init() override {
-    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    auto g = this->get_graph();
+    const std::size_t n = (std::size_t)g.get_number_of_vertices();
     previous.resize(n);
     out_scale.resize(n);
+    if (pull) {
+      contribution.resize(n);
+      auto in = g.in_edges();
+      std::vector<edge_t> offsets(n + 1);
+      GRX_HIP_CHECK(hipMemcpy(offsets.data(), in.get_row_offsets(), (n + 1) * sizeof(edge_t),
+                              hipMemcpyDeviceToHost));
+      std::vector<hub_chunk_t> chunks;
+      for (std::size_t v = 0; v < n; ++v) {
+        const unsigned deg = (unsigned)(offsets[v + 1] - offsets[v]);
+        if (deg < hip::kernels::RED_HUB)
+          continue;
+        for (unsigned off = 0; off < deg; off += hip::kernels::RED_CHUNK) {
+          hub_chunk_t c;
+          c.row = (vertex_t)v;
+          c.first = offsets[v] + (edge_t)off;
+          c.count = (int)((deg - off < hip::kernels::RED_CHUNK) ? deg - off : hip::kernels::RED_CHUNK);
+          chunks.push_back(c);
+        }
+      }
+      hub_chunks.assign(chunks);
+    }
   }
   void reset() override {
     auto ctx = this->get_single_context();
@@ -408,6 +438,82 @@ struct pr_enactor_t : gunrock::enactor_t<problem_type> {
     operators::advance::execute<lb, operators::advance_direction_t::forward,
                                 operators::advance_io_type_t::graph,
                                 operators::advance_io_type_t::none>(G, E, spread, context);
+  }
+
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (this->iteration == 0)
+      return false;
+    if (max_iterations && this->iteration >= max_iterations)
+      return true;
+    auto P = this->get_problem();
+    auto ctx = context.get_context(0);
+    const std::size_t n = (std::size_t)P->get_graph().get_number_of_vertices();
+    weight_t* rank = P->rank;
+    weight_t* previous = P->previous.data();
+    const weight_t err = hip::transform_reduce(
+        n,
+        [rank, previous] __device__(std::size_t i) -> weight_t {
+          weight_t d = rank[i] - previous[i];
+          return d < 0 ? -d : d;
+        },
+        weight_t(0), rocprim::maximum<weight_t>(), *ctx);
+    return err < P->tol;
+  }
+};
+
+/// PageRank, PULL formulation: p[v] = (1 - alpha + dangling) / n + sum over IN-edges (u -> v) of
+/// p_prev[u] * scale[u] * w -- the same quantities as the push client above (and pr.hxx), summed
+/// per destination instead of scattered with one float atomic per edge.  Needs in-edges (an
+/// undirected graph, or a directed one with an attached transpose).  New relative to the
+/// reference; float sums are taken in a different order, hence a tolerance against the push form.
+template <typename problem_type>
+struct pr_pull_enactor_t : gunrock::enactor_t<problem_type> {
+  using base_t = gunrock::enactor_t<problem_type>;
+  using vertex_t = typename problem_type::vertex_t;
+  using edge_t = typename problem_type::edge_t;
+  using weight_t = typename problem_type::weight_t;
+  int max_iterations = 0;
+
+  pr_pull_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
+                    enactor_properties_t props)
+      : base_t(p, ctx, props) {}
+
+  void loop(gcuda::multi_context_t& context) override {
+    namespace k = hip::kernels;
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    auto ctx = context.get_context(0);
+    error::throw_if_exception(!G.can_pull(), "pull PageRank needs in-edges (attach a transpose)");
+    const std::size_t n = (std::size_t)G.get_number_of_vertices();
+    weight_t* rank = P->rank;
+    weight_t* previous = P->previous.data();
+    weight_t* scale = P->out_scale.data();
+    weight_t* give = P->contribution.data();
+    const weight_t alpha = P->alpha;
+
+    GRX_HIP_CHECK(hipMemcpyAsync(previous, rank, n * sizeof(weight_t), hipMemcpyDeviceToDevice,
+                                 ctx->stream()));
+    hip::for_each_index(
+        n, [previous, scale, give] __device__(std::size_t i) { give[i] = previous[i] * scale[i]; },
+        ctx->stream());
+    const weight_t dangling = hip::transform_reduce(
+        n,
+        [previous, scale, alpha] __device__(std::size_t i) -> weight_t {
+          return scale[i] == 0 ? alpha * previous[i] : weight_t(0);
+        },
+        weight_t(0), rocprim::plus<weight_t>(), *ctx);
+    const weight_t base = (1 - alpha + dangling) / (weight_t)n;
+    auto in = G.in_edges();
+    const unsigned grid = (unsigned)ctx->compute_units() * 8;
+    k::row_group_sum_kernel<<<grid, k::RED_BLOCK, 0, ctx->stream()>>>(in, give, base, rank);
+    GRX_HIP_CHECK(hipGetLastError());
+    if (P->hub_chunks.size()) {
+      const std::size_t chunks = P->hub_chunks.size();
+      const unsigned hub_grid = (unsigned)(chunks < grid ? chunks : grid);
+      k::hub_chunk_sum_kernel<<<hub_grid, k::RED_BLOCK, 0, ctx->stream()>>>(
+          in, give, P->hub_chunks.data(), chunks, rank);
+      GRX_HIP_CHECK(hipGetLastError());
+    }
   }
 
   bool is_converged(gcuda::multi_context_t& context) override {

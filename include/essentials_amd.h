@@ -96,8 +96,11 @@ typedef struct grx_options {
   float frontier_sizing_factor; /* 0: default 1.5 (enactor.hxx:36)                                */
   int32_t collect_kernel_time;  /* 1: event-time the advance kernels (adds two events per launch)  */
   int32_t chunk_edges;          /* 0: default (1024): edges per chunk of a hub list                */
-  int32_t direction_optimized;  /* grx_bfs only. 0: push every level (what bfs.hxx does); 1: pull the
-                                   wide levels (advance_direction_t::backward) -- undirected graphs */
+  int32_t direction_optimized;  /* grx_bfs: 0 push every level (what bfs.hxx does); 1 pull the wide
+                                   levels (advance_direction_t::backward).  grx_pagerank: 0 the push
+                                   scatter of pr.hxx (one float atomic per edge); 1 the pull form (sums
+                                   per destination over in-edges, no atomics).  Pulling needs in-edges:
+                                   an undirected graph or grx_graph_build_in_edges                  */
   float do_alpha;               /* 0: default 4: pull when frontier edges > unexplored edges/alpha   */
   float do_beta;                /* 0: default 24: push again when frontier vertices < |V| / beta     */
   int32_t chunk_queue_limit;    /* test hook, 0: none. Caps the hub chunk queue to force the overflow

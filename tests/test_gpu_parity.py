@@ -167,6 +167,26 @@ def test_pagerank_against_restatement(ea, ctx, oracle, lb):
         assert abs(st.iterations - it) <= 1
 
 
+def test_pagerank_pull_matches_push_and_restatement(ea, ctx, oracle):
+    """The pull form (sums per destination over in-edges, no atomics; new relative to pr.hxx)
+    converges to the same ranks as the push scatter and the oracle's restatement; directed graphs
+    get their transpose attached first (a graph without one is taken to be undirected)."""
+    for scale, sym in ((10, False), (12, True), (13, False)):
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, 16, 3, 5, sym)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        if not sym:
+            G.build_in_edges(ctx)
+        p, st = ea.pagerank(ctx, G, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
+        push, st_push = ea.pagerank(ctx, G, 0.85, 1e-6)
+        want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+        p, push = host(p), host(push)
+        assert st.pull_iterations == st.iterations and st_push.pull_iterations == 0
+        assert abs(float(p.sum()) - 1.0) < 1e-3
+        assert np.abs(p - want).max() < 5e-6, (scale, np.abs(p - want).max())
+        assert np.abs(p - push).max() < 5e-6
+        assert abs(st.iterations - it) <= 1
+
+
 # ---------------------------------------------------------------------------
 # operators
 # ---------------------------------------------------------------------------

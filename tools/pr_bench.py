@@ -22,6 +22,15 @@ for lb in a.lbs.split(","):
     nbytes = (12 * g.nnz + 44 * g.n_rows) * it
     print(f"pr {lb:13s} {best.elapsed_ms:8.2f} ms {it} iters  {best.elapsed_ms/it:7.3f} ms/iter  advance {best.advance_kernel_ms/it:7.3f} ms/iter "
           f"{g.nnz*it/best.elapsed_ms/1e6:7.2f} GTEPS  algorithmic {nbytes/best.elapsed_ms/1e6:7.1f} GB/s  sum={float(p.sum()):.6f}", flush=True)
+g.build_in_edges(ctx)   # transpose for the pull form
+best = None
+for r in range(3):
+    p, st = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
+    if best is None or st.elapsed_ms < best.elapsed_ms: best = st
+it = best.iterations
+nbytes = (12 * g.nnz + 44 * g.n_rows) * it
+print(f"pr PULL          {best.elapsed_ms:8.2f} ms {it} iters  {best.elapsed_ms/it:7.3f} ms/iter  "
+      f"{g.nnz*it/best.elapsed_ms/1e6:7.2f} GTEPS  algorithmic {nbytes/best.elapsed_ms/1e6:7.1f} GB/s  sum={float(p.sum()):.6f}", flush=True)
 if a.cpu:
     from oracle.oracle import Oracle
     o = Oracle(); Ap, Aj, Ax = g.to_host()
