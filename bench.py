@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--weight-seed", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pagerank", action="store_true")
+    ap.add_argument("--pagerank-scale", type=int, default=24)
     ap.add_argument("--algo", default="bfs+sssp", choices=["bfs+sssp", "bfs", "sssp"])
     return ap.parse_args()
 
@@ -99,6 +101,26 @@ def cpu_baseline(Ap, Aj, Ax, algo):
     return {"value": edges / (ms * 1e-3) / 1e6, "unit": "MTEPS", "cores": 1, "kind": kind,
             "sample": f"one {algo} from source 0 on the same R-MAT graph, search loops only "
                       f"({ms:.0f} ms of {time.time() - t0:.0f} s wall)"}
+
+
+def pagerank_leg(ea, ctx, a) -> dict:
+    """BASELINE configs[3] stand-in, reported beside the headline (outside the timed region): PageRank
+    on a DIRECTED R-MAT graph, the push scatter pr.hxx performs and the pull form."""
+    try:
+        g = ea.Graph.rmat(ctx, a.pagerank_scale, a.edge_factor, a.seed, 0, False)
+        out = {"workload": f"PageRank alpha 0.85 tol 1e-6 on directed RMAT scale-{a.pagerank_scale} "
+                           f"edgefactor-{a.edge_factor} ({g.nnz} edges)"}
+        _, st = ea.pagerank(ctx, g, 0.85, 1e-6)
+        out["push"] = {"iterations": st.iterations, "ms_per_iteration": st.elapsed_ms / st.iterations,
+                       "mteps": g.nnz * st.iterations / st.elapsed_ms / 1e3}
+        g.build_in_edges(ctx)
+        _, st = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
+        out["pull"] = {"iterations": st.iterations, "ms_per_iteration": st.elapsed_ms / st.iterations,
+                       "mteps": g.nnz * st.iterations / st.elapsed_ms / 1e3}
+        g.close()
+        return out
+    except Exception as e:   # never lose the headline line to the side leg
+        return {"error": str(e)}
 
 
 def main():
@@ -213,6 +235,8 @@ def main():
     if world == 1 and "bfs" in a.algo:
         out["bfs_direction_optimized"] = runner.bfs_direction_optimized(
             sources[a.warmup:a.warmup + min(a.steps, 8)], lb)
+    if world == 1 and not a.no_pagerank:
+        out["pagerank"] = pagerank_leg(ea, ctx, a)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # timed on the host cores at N = 1 only
             Ap, Aj, Ax = runner.host_csr()

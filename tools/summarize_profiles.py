@@ -133,7 +133,7 @@ latest = {
     "command": "tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc TCC_BUSY_sum "
                "TCC_CYCLE_sum TCC_REQ_sum TCC_TAG_STALL_sum | --pmc TCC_HIT_sum TCC_MISS_sum TCC_READ_sum "
                "TCC_READ_SECTORS_sum (four separate runs) -- python3 bench.py --steps 2 --warmup 1 "
-               "--no-cpu-baseline --algo bfs",
+               "--no-cpu-baseline --no-pagerank --algo bfs",
     "kernels": "block_mapped_kernel + chunk_kernel of the push BFS client, all levels of one traversal",
     "traversals_in_command": trav,
     "FETCH_SIZE_KB_per_traversal": adv_fetch / trav if trav else None,
