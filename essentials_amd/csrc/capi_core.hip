@@ -18,6 +18,34 @@ std::string& last_error() {
 
 using namespace essentials_amd;
 
+namespace {
+__global__ void __launch_bounds__(256)
+    offsets_max_degree_kernel(const int32_t* ap, int32_t n, unsigned long long* out) {
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned long long d = (unsigned long long)(ap[i + 1] - ap[i]);
+    local = d > local ? d : local;
+  }
+  local = gunrock::hip::wave_max(local);
+  if ((threadIdx.x & 63) == 0 && local)
+    atomicMax(out, local);
+}
+}  // namespace
+
+unsigned long long essentials_amd::reduce_max_degree(const int32_t* d_row_offsets, int32_t n_rows) {
+  if (!d_row_offsets || n_rows < 1)
+    return 0;
+  gunrock::hip::buffer_t<unsigned long long> out(1);
+  GRX_HIP_CHECK(hipMemset(out.data(), 0, sizeof(unsigned long long)));
+  const int64_t blocks = ((int64_t)n_rows + 255) / 256;
+  offsets_max_degree_kernel<<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256>>>(d_row_offsets, n_rows,
+                                                                                 out.data());
+  GRX_HIP_CHECK(hipGetLastError());
+  unsigned long long md = 0;
+  GRX_HIP_CHECK(hipMemcpy(&md, out.data(), sizeof md, hipMemcpyDeviceToHost));
+  return md;
+}
+
 extern "C" {
 
 int grx_abi_version(void) { return GRX_ABI_VERSION; }

@@ -66,6 +66,11 @@ struct grx_context_s {
   gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
 };
 
+namespace essentials_amd {
+/// max over rows of (offsets[i + 1] - offsets[i]) of a device CSR; synchronous (capi_core.hip).
+unsigned long long reduce_max_degree(const int32_t* d_row_offsets, int32_t n_rows);
+}  // namespace essentials_amd
+
 struct grx_graph_s {
   int32_t n_rows = 0, n_cols = 0;
   int64_t nnz = 0;
@@ -78,11 +83,21 @@ struct grx_graph_s {
   // optional in-edge arrays (grx_graph_build_in_edges): marks the graph directed
   std::unique_ptr<gunrock::graph::transposed_t<int32_t, int32_t, float>> in_edges;
 
+  // largest out-degree, reduced on first use (the CSR arrays of a handle do not change)
+  mutable unsigned long long max_degree = 0;
+  mutable bool max_degree_known = false;
+
   essentials_amd::graph_type view() const {
     using namespace gunrock;
     auto G = graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
         n_rows, n_cols, (int32_t)nnz, const_cast<int32_t*>(d_ap), const_cast<int32_t*>(d_aj),
         const_cast<float*>(d_ax));
+    if (!max_degree_known) {
+      max_degree = essentials_amd::reduce_max_degree(d_ap, n_rows);
+      max_degree_known = true;
+    }
+    // never 0 ("unknown"): an edgeless graph reports 1, which only loosens a sizing bound
+    G.properties.max_degree = max_degree ? max_degree : 1ull;
     if (in_edges) {
       G.properties.directed = true;
       in_edges->attach_to(G);

@@ -139,10 +139,13 @@ struct clocked_t {
 
 template <typename graph_t>
 unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
+  if (G.properties.max_degree)  // the view's builder knows it
+    return G.properties.max_degree;
   auto& ws = ctx.workspace();
   const void* key = (const void*)G.get_row_offsets();
   const std::size_t n = (std::size_t)G.get_number_of_vertices();
-  if (auto* f = ws.find_graph(key, n))
+  const std::size_t m = (std::size_t)G.get_number_of_edges();
+  if (auto* f = ws.find_graph(key, n, m))
     return f->max_degree;
   unsigned long long* counters = ws.counters();
   if (n) {
@@ -154,7 +157,7 @@ unsigned long long max_degree(graph_t& G, gcuda::standard_context_t& ctx) {
   if (std::getenv("GRX_DEBUG"))
     std::fprintf(stderr, "[grx] max_degree(%zu vertices) = %llu (seq %llu)\n", n, md,
                  ws.mirror()[gcuda::workspace_t::sequence_slot]);
-  gcuda::workspace_t::graph_facts_t facts{key, n, md};
+  gcuda::workspace_t::graph_facts_t facts{key, n, md, m};
   return ws.remember_graph(facts)->max_degree;
 }
 
@@ -332,7 +335,9 @@ void execute(graph_t& G,
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,
                                                       hub_threshold, chunk_edges, nullptr, tile_width);
-    if (max_deg >= hub_threshold) {
+    (void)max_deg;  // sizing only: whether hub chunks were queued is the DEVICE's knowledge, and a
+                    // remembered max degree (keyed by address) must never decide if they are expanded
+    {
       const unsigned chunk_grid =
           (unsigned)context.compute_units() * context.options().chunk_blocks_per_cu;
       if (context.options().wave_chunks)
@@ -385,8 +390,8 @@ void enqueue_packed(graph_t& G,
   k::block_mapped_kernel<false, false, vin, vin><<<grid, k::ADV_BLOCK, 0, context.stream()>>>(
       G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, hub_threshold,
       chunk_edges, n_in_device);
-  if (max_deg >= hub_threshold)
-    k::chunk_kernel<vin><<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu,
+  (void)max_deg;
+  k::chunk_kernel<vin><<<(unsigned)context.compute_units() * context.options().chunk_blocks_per_cu,
                            k::ADV_BLOCK, 0, context.stream()>>>(G, op, chunks, chunk_capacity, output,
                                                                 capacity, counters);
   GRX_HIP_CHECK(hipGetLastError());

@@ -30,6 +30,11 @@ using memory::memory_space_t;
 struct graph_properties_t {
   bool directed{false};
   bool weighted{true};
+  /// Largest out-degree when the builder of the view knows it (0 = unknown).  Operators that
+  /// need it otherwise reduce it once per context and remember it by (offsets pointer, |V|, |E|)
+  /// -- which cannot tell apart two graphs built one after the other in the same memory, so
+  /// owners of long-lived graphs should set it (the C ABI's graph handles do).
+  unsigned long long max_degree{0};
 };
 
 enum view_t : uint32_t { invalid = 1u << 0, csr = 1u << 1, csc = 1u << 2, coo = 1u << 3 };

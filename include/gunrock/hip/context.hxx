@@ -126,13 +126,16 @@ class workspace_t {
     const void* key = nullptr;
     std::size_t vertices = 0;
     unsigned long long max_degree = 0;
+    std::size_t edges = 0;
   };
-  graph_facts_t* find_graph(const void* key, std::size_t vertices) {
+  graph_facts_t* find_graph(const void* key, std::size_t vertices, std::size_t edges) {
     for (auto& g : graphs_)
-      if (g.key == key && g.vertices == vertices)
+      if (g.key == key && g.vertices == vertices && g.edges == edges)
         return &g;
     return nullptr;
   }
+  /// Call when graph memory is released or rewritten: remembered facts are keyed by address.
+  void forget_graphs() { graphs_.clear(); }
   graph_facts_t* remember_graph(const graph_facts_t& g) {
     graphs_.push_back(g);
     return &graphs_.back();

@@ -1,6 +1,8 @@
 """Randomised parity sweeps and the rarely-taken paths of the advance kernels: tiny hub
 thresholds / chunk sizes, a capped chunk queue (overflow -> hubs expanded in place), output
 frontiers that must grow, many sources.  Everything is checked against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,9 +65,10 @@ def test_output_frontier_grows_when_needed(env, oracle):
 
 def test_random_graphs_sources_schedules(env, oracle):
     ea, ctx, torch = env
-    rng = np.random.default_rng(2026)
+    # GRX_STRESS_SEED / GRX_STRESS_TRIALS: longer soaks with other seeds (default: the fixed 12)
+    rng = np.random.default_rng(int(os.environ.get("GRX_STRESS_SEED", "2026")))
     lbs = ["block_mapped", "merge_path", "bucketing", "work_stealing", "thread_mapped", "warp_mapped"]
-    for trial in range(12):
+    for trial in range(int(os.environ.get("GRX_STRESS_TRIALS", "12"))):
         scale = int(rng.integers(5, 15))
         ef = int(rng.integers(1, 24))
         sym = bool(rng.integers(0, 2))
@@ -88,3 +91,28 @@ def test_random_graphs_sources_schedules(env, oracle):
                 d2, _ = ea.bfs(ctx, G, int(s), options=ea.Options(direction_optimized=True,
                                                                    do_alpha=float(rng.choice([0.5, 4, 1e6]))))
                 assert (host(d2) == want).all(), (trial, "do", s)
+
+
+def test_graph_rebuilt_in_the_same_memory(env, oracle):
+    """Regression (found by a 200-trial soak): the engine remembered a graph's max degree by the
+    address of its row offsets; a hub-less graph followed by a hub graph of the same shape in the
+    same (freed and reused) memory then skipped the hub chunk kernel and lost edges.  Handles now
+    carry their own max degree and queued chunks are always expanded."""
+    ea, ctx, torch = env
+    n = 1024
+    # ring: every degree 1 -> no hubs
+    ring_ap = np.arange(n + 1, dtype=np.int32)
+    ring_aj = ((np.arange(n) + 1) % n).astype(np.int32)
+    ones = np.ones(n, np.float32)
+    # star with the same |V| and |E|: vertex 0 -> 1..1023, and 1 -> 0
+    star_ap = np.concatenate([[0], np.full(1, n - 1), np.full(n - 1, n)]).astype(np.int32)
+    star_aj = np.concatenate([np.arange(1, n), [0]]).astype(np.int32)
+    for _ in range(4):   # alternate so that the allocator hands the same blocks back
+        for Ap, Aj in ((ring_ap, ring_aj), (star_ap, star_aj)):
+            G = ea.Graph.from_host_csr(Ap, Aj, ones)
+            want, _ = oracle.bfs_heap(Ap, Aj, 0)
+            for opts in (ea.Options(), ea.Options(load_balance=ea.LoadBalance.bucketing),
+                         ea.Options(load_balance=ea.LoadBalance.work_stealing)):
+                d, _ = ea.bfs(ctx, G, 0, options=opts)
+                assert (host(d) == want).all()
+            G.close()
