@@ -13,6 +13,9 @@ import pytest
 
 from conftest import GOLDEN_DIR, golden_graph
 
+# GRX_STRESS_SEED shifts the seeds of the randomised operator tests (soaks)
+SEED_OFFSET = int(os.environ.get("GRX_STRESS_SEED", "0"))
+
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 
 INF_I = 2**31 - 1
@@ -204,7 +207,7 @@ def _frontier_cases(n, rng):
 @pytest.mark.parametrize("lb", ALL_LB)
 @pytest.mark.parametrize("holes", [False, True])
 def test_advance_matches_oracle(ea, ctx, torch, oracle, lb, holes):
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SEED_OFFSET)
     for (scale, ef, sym) in ((6, 4, True), (9, 8, False), (11, 16, True)):
         n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, 21, 9, sym)
         G = ea.Graph.from_host_csr(Ap, Aj, Ax)
@@ -263,7 +266,7 @@ def test_advance_capacity_error(ea, ctx, torch, oracle):
 
 @pytest.mark.parametrize("alg", ["remove", "predicated", "compact", "bypass"])
 def test_filter_matches_oracle(ea, ctx, torch, oracle, alg):
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + SEED_OFFSET)
     n, Ap, Aj, Ax = oracle.rmat_csr(8, 4, 1, 0, True)
     G = ea.Graph.from_host_csr(Ap, Aj, Ax)
     for size in (0, 1, 63, 64, 65, 1023, 1024, 1025, 5000, 100000):
@@ -292,7 +295,7 @@ def test_filter_matches_oracle(ea, ctx, torch, oracle, alg):
 
 @pytest.mark.parametrize("alg", ["unique", "unique_copy"])
 def test_uniquify_matches_oracle(ea, ctx, torch, oracle, alg):
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 + SEED_OFFSET)
     for size in (0, 1, 2, 64, 1000, 1025, 70000):
         f = rng.integers(0, max(size // 3, 2), size).astype(np.int32)
         ft = torch.from_numpy(f).cuda()
@@ -310,7 +313,7 @@ def test_bfs_sssp_rmat18_against_oracle(ea, ctx, oracle, lb):
     g = ea.Graph.rmat(ctx, 18, 16, seed=1, weight_seed=7)
     Ap, Aj, Ax = g.to_host()
     deg = np.diff(Ap)
-    rng = np.random.default_rng(18)
+    rng = np.random.default_rng(18 + SEED_OFFSET)
     sources = [0] + rng.choice(np.flatnonzero(deg > 0), 2).tolist()
     for s in sources:
         d, st = ea.bfs(ctx, g, int(s), options=ea.Options(load_balance=ea.LoadBalance[lb]))
@@ -475,7 +478,7 @@ def test_sssp_fractional_weights_within_one_ulp(ea, ctx, torch, oracle):
     """north_star: SSSP distances within 1 ULP.  With arbitrary float weights every candidate
     distance is a left-to-right path sum and float addition is monotone, so the fix point is the
     same as the reference checker's; the test allows 1 ULP and reports exact equality."""
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(4 + SEED_OFFSET)
     n, Ap, Aj, _ = oracle.rmat_csr(14, 16, 1, 0)
     Aj = np.ascontiguousarray(Aj)
     Ax = (rng.random(len(Aj)) * 9.9 + 0.1).astype(np.float32)

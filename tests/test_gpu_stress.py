@@ -116,3 +116,57 @@ def test_graph_rebuilt_in_the_same_memory(env, oracle):
                 d, _ = ea.bfs(ctx, G, 0, options=opts)
                 assert (host(d) == want).all()
             G.close()
+
+
+def test_random_partitioned_protocol_world1(env, oracle):
+    """The superstep protocol with random slot sizes and dense-exchange thresholds (pairs / level
+    bitmaps / replica all-reduce, fused and two-call loops) on random graphs: world = 1 exercises
+    every device kernel of the exchange; GRX_STRESS_TRIALS lengthens it."""
+    ea, ctx0, torch = env
+    from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
+    rng = np.random.default_rng(int(os.environ.get("GRX_STRESS_SEED", "2026")) + 1)
+    stream = torch.cuda.Stream()
+    ctx = ea.Context(0, stream=stream.cuda_stream)
+    for trial in range(max(4, int(os.environ.get("GRX_STRESS_TRIALS", "12")) // 3)):
+        scale = int(rng.integers(5, 14))
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, int(rng.integers(1, 20)), int(rng.integers(1, 1 << 30)), 7,
+                                        bool(rng.integers(0, 2)))
+        Aj = np.ascontiguousarray(Aj); Ax = np.ascontiguousarray(Ax)
+        g = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        fused = bool(rng.integers(0, 2))
+        kw = dict(small_slot=int(rng.choice([2, 8, 64, 1 << 15])), fused=fused, stream=stream,
+                  dense_threshold=int(rng.choice([0, 4, 64, 1 << 30])),
+                  replica_threshold=int(rng.choice([0, 4, 64, 1 << 30])))
+        trav = PartitionedTraversal(HipKernels(ctx, g), None, 0, 1, n, 0, n, g.nnz, "cuda:0", **kw)
+        for s in rng.integers(0, n, 2):
+            depth = torch.empty(n, dtype=torch.int32, device="cuda")
+            trav.run(OP_BFS, int(s), depth)
+            want, _ = oracle.bfs_heap(Ap, Aj, int(s))
+            assert (depth.cpu().numpy() == want).all(), (trial, kw, s)
+            w = torch.empty(n, dtype=torch.float32, device="cuda")
+            trav.run(OP_SSSP, int(s), w)
+            wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, int(s))
+            assert (w.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all(), (trial, kw, s)
+        g.close()
+
+
+def test_random_pagerank_pull_and_push(env, oracle):
+    """Pull and push PageRank against the oracle's pr.hxx restatement on random graphs (directed
+    ones with their transpose attached): row groups, hub chunks and dangling vertices all occur."""
+    ea, ctx, torch = env
+    rng = np.random.default_rng(int(os.environ.get("GRX_STRESS_SEED", "2026")) + 2)
+    for trial in range(max(3, int(os.environ.get("GRX_STRESS_TRIALS", "12")) // 4)):
+        scale = int(rng.integers(4, 14))
+        sym = bool(rng.integers(0, 2))
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, int(rng.integers(1, 40)), int(rng.integers(1, 1 << 30)),
+                                        int(rng.integers(0, 9)), sym)
+        Aj = np.ascontiguousarray(Aj); Ax = np.ascontiguousarray(Ax)
+        g = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        if not sym:
+            g.build_in_edges(ctx)
+        want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+        for pull in (True, False):
+            p, st = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=pull))
+            p = host(p)
+            assert np.abs(p - want).max() < 5e-6 and abs(st.iterations - it) <= 1, (trial, pull, scale, sym)
+        g.close()
