@@ -139,7 +139,9 @@ int grx_context_device_info(grx_context_t ctx, int32_t* compute_units, int32_t* 
                             int64_t* total_memory_bytes, char* name, size_t name_len);
 
 /* ---- graph: graph::build::from_csr<device, view_t::csr> ------------------ */
-/* Non-owning view over caller-owned device CSR arrays (graph/graph.hxx:159-168). */
+/* Non-owning view over caller-owned device CSR arrays (graph/graph.hxx:159-168).  The arrays must
+ * be complete when the handle is first used (synchronise the stream that produced them) and must
+ * not change while it lives: the handle reduces and keeps the graph's largest degree. */
 int grx_graph_from_device_csr(int32_t n_rows, int32_t n_cols, int32_t nnz,
                               const int32_t* d_row_offsets, const int32_t* d_col,
                               const float* d_val, grx_graph_t* out);
