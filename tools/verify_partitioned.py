@@ -13,7 +13,11 @@ from essentials_amd import api
 from essentials_amd.distributed import HipKernels, PartitionedTraversal, OP_BFS, OP_SSSP
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
-sources = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 12345]
+sources = ([int(x) for x in sys.argv[2].split(",")]
+           if len(sys.argv) > 2 and sys.argv[2] != "soak" else [0, 12345])
+# optional soak: verify_partitioned.py SCALE soak SECONDS SEED -- random sources, slot sizes and
+# dense-exchange thresholds (the same draws on every rank) until the time is up
+soak = len(sys.argv) > 2 and sys.argv[2] == "soak"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -29,6 +33,38 @@ with torch.cuda.stream(stream):
     trav = PartitionedTraversal(HipKernels(ctx, local), dist, rank, world, full.n_rows, lo.value,
                                 hi.value, local.nnz, "cuda:0", stream=stream)
 bad = 0
+if soak:
+    import time
+    import numpy as np
+    budget, rng = float(sys.argv[3]), np.random.default_rng(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+    n, runs, t0 = full.n_rows, 0, time.time()
+    go = torch.ones(1)
+    while True:
+        go[0] = 1.0 if time.time() - t0 < budget else 0.0
+        dist.broadcast(go, 0)           # rank 0's clock decides for everybody
+        if not bool(go[0]):
+            break
+        kw = dict(small_slot=int(rng.choice([8, 512, 1 << 15])),
+                  dense_threshold=int(rng.choice([0, 64, n // 64, 1 << 30])),
+                  replica_threshold=int(rng.choice([0, 64, n // max(world, 1), 1 << 30])))
+        with torch.cuda.stream(stream):
+            t = PartitionedTraversal(HipKernels(ctx, local), dist, rank, world, n, lo.value, hi.value,
+                                     local.nnz, "cuda:0", stream=stream, **kw)
+        for s in rng.integers(0, n, 3):
+            s = int(s)
+            want_d, _ = ea.bfs(ctx, full, s)
+            want_w, _ = ea.sssp(ctx, full, s)
+            ctx.synchronize()
+            depth = torch.empty(n, dtype=torch.int32, device="cuda"); t.run(OP_BFS, s, depth)
+            w = torch.empty(n, dtype=torch.float32, device="cuda"); t.run(OP_SSSP, s, w)
+            torch.cuda.synchronize()
+            ok = torch.equal(depth, want_d) and torch.equal(w.view(torch.int32), want_w.view(torch.int32))
+            runs += 1
+            if not ok:
+                bad += 1
+                print(f"[rank {rank}] MISMATCH source {s} {kw}", flush=True)
+    print(f"[rank {rank}/{world}] soak scale {scale}: {runs} sources, {bad} mismatches", flush=True)
+    sources = []
 for s in sources:
     want_d, _ = ea.bfs(ctx, full, s)
     want_w, _ = ea.sssp(ctx, full, s)
