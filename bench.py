@@ -8,8 +8,12 @@ random non-isolated vertices) through the HIP path (`libessentials_amd.so`).  Th
 generated on the GPU and is resident in HBM before the timed region; labels stay on the device.
 `value` = (sum over steps of the out-degrees of the vertices each traversal reached, BFS and
 SSSP both) / wall time of the K steps (barrier + synchronize on both sides, max over ranks).
-Prints ONE JSON line (rank 0).  For N > 1 launch with
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
+Prints ONE JSON line (rank 0).  N > 1: either launched by
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or invoked directly as
+`python bench.py --gpus N`: the parent then makes NO GPU call, starts N fresh child processes (one
+rank per GPU) with that environment, relays rank 0's line and exits with the children's status.
+GRX_BENCH_BACKEND=gloo rehearses the N > 1 path with the ranks sharing one GPU.
 
 Extra objects on the line (prompt section 4):
   roofline     dominant kernel = the BFS advance kernels; achieved = algorithmic bytes of one BFS
@@ -123,8 +127,56 @@ def pagerank_leg(ea, ctx, a) -> dict:
         return {"error": str(e)}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` invoked directly: start N child ranks and relay rank 0's line.
+    This process has not touched the GPU (no torch import, no HIP call) and never does: the ranks
+    are fresh child processes, not an exec of this one."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(free_port())
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                # one rank failed: the others would wait in a collective for ever -- stop exactly
+                # the processes started above, then report
+                for q in live:
+                    q.kill()
+    reader.join(timeout=10)
+    sys.stdout.write("".join(chunks))
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))
     import numpy as np
     import torch
     import essentials_amd as ea
@@ -133,8 +185,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     # GRX_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU
     backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
     device = local_rank % max(torch.cuda.device_count(), 1)
