@@ -140,6 +140,8 @@ _SIGNATURES = {
     "grx_context_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "grx_context_destroy": (C.c_int, [_VP]),
     "grx_context_synchronize": (C.c_int, [_VP]),
+    "grx_context_wait_stream": (C.c_int, [_VP, _VP]),
+    "grx_trim_cache": (C.c_int, []),
     "grx_context_device_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]),
     "grx_graph_from_device_csr": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP,
@@ -244,9 +246,25 @@ class Context:
         _check(load_library().grx_context_create(device, stream, C.byref(self._h)),
                "grx_context_create")
         self.device = device
+        self._stream = stream   # None: the engine's private non-blocking stream
 
     def synchronize(self) -> None:
         _check(load_library().grx_context_synchronize(self._h), "grx_context_synchronize")
+
+    def after_torch(self) -> None:
+        """Order the engine's next work after everything torch has enqueued on ITS current stream
+        of this device (event record + stream wait on the device; the host does not wait).  A
+        default Context runs on a private non-blocking stream that is ordered after nothing:
+        tensors a caller has just filled (`torch.full`, `clone`, `copy_`) must not be read by an
+        engine kernel before the fill has run.  Every wrapper below that takes tensors calls this;
+        it is a no-op when the context was created on torch's current stream."""
+        import torch
+        if not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if self._stream is not None and cur == self._stream:
+            return
+        _check(load_library().grx_context_wait_stream(self._h, cur), "grx_context_wait_stream")
 
     def device_info(self) -> dict:
         cus, wave, mem = C.c_int32(), C.c_int32(), C.c_int64()
@@ -261,6 +279,12 @@ class Context:
         _check(load_library().grx_measure_copy_bandwidth(self._h, nbytes, repeats, g),
                "grx_measure_copy_bandwidth")
         return g.value
+
+    @staticmethod
+    def trim_cache() -> None:
+        """Return the device blocks the engine parked for reuse to the device (see
+        grx_trim_cache): for hosts whose OTHER allocator (torch) runs short."""
+        _check(load_library().grx_trim_cache(), "grx_trim_cache")
 
     def gather_rate(self, graph, mode: int = 1, repeats: int = 5) -> float:
         """Random-gather ceiling of `graph` in lookups (= edges) per second: table[column[i]] over
@@ -310,6 +334,8 @@ class Graph:
         """Non-owning view over torch int32/int32/float32 device tensors (kept alive here)."""
         h = _VP()
         n = row_offsets.numel() - 1
+        # the handle reduces the largest degree from the arrays on first use: they must be complete
+        _torch().cuda.current_stream(row_offsets.device).synchronize()
         _check(load_library().grx_graph_from_device_csr(n, n, col.numel(), _ptr(row_offsets),
                                                         _ptr(col), _ptr(val), C.byref(h)),
                "grx_graph_from_device_csr")
@@ -391,6 +417,7 @@ def bfs(ctx: Context, g: Graph, source: int, distances=None, options: Optional[O
         distances = torch.empty(g.n_rows, dtype=torch.int32, device=f"cuda:{ctx.device}")
     o = (options or Options())._c()
     s = _Stats()
+    ctx.after_torch()
     _check(load_library().grx_bfs(ctx._h, g._h, source, _ptr(distances), None, C.byref(o),
                                   C.byref(s)), "grx_bfs")
     return distances, Stats._from(s)
@@ -403,6 +430,7 @@ def sssp(ctx: Context, g: Graph, source: int, distances=None, options: Optional[
         distances = torch.empty(g.n_rows, dtype=torch.float32, device=f"cuda:{ctx.device}")
     o = (options or Options())._c()
     s = _Stats()
+    ctx.after_torch()
     _check(load_library().grx_sssp(ctx._h, g._h, source, _ptr(distances), None, C.byref(o),
                                    C.byref(s)), "grx_sssp")
     return distances, Stats._from(s)
@@ -416,6 +444,7 @@ def pagerank(ctx: Context, g: Graph, alpha: float = 0.85, tol: float = 1e-6, p=N
         p = torch.empty(g.n_rows, dtype=torch.float32, device=f"cuda:{ctx.device}")
     o = (options or Options())._c()
     s = _Stats()
+    ctx.after_torch()
     _check(load_library().grx_pagerank(ctx._h, g._h, alpha, tol, _ptr(p), C.byref(o), C.byref(s)),
            "grx_pagerank")
     return p, Stats._from(s)
@@ -440,6 +469,7 @@ def advance(ctx: Context, g: Graph, frontier, op: EdgeOp = EdgeOp.all, state=Non
         cap = capacity if capacity is not None else max(int(g.nnz) * 2 + 16, 16)
         out = torch.empty(cap, dtype=torch.int32, device=f"cuda:{ctx.device}")
     n_out = C.c_int64()
+    ctx.after_torch()
     _check(load_library().grx_advance(ctx._h, g._h, C.byref(o), int(op), _ptr(state), iparam,
                                       _ptr(frontier), n_in, _ptr(out), cap, C.byref(n_out)),
            "grx_advance")
@@ -453,6 +483,7 @@ def filter(ctx: Context, g: Graph, frontier, algorithm: FilterAlgorithm,
     n_in = frontier.numel()
     out = torch.empty(max(n_in, 1), dtype=torch.int32, device=f"cuda:{ctx.device}")
     n_out = C.c_int64()
+    ctx.after_torch()
     _check(load_library().grx_filter(ctx._h, g._h, int(algorithm), int(pred), _ptr(state), iparam,
                                      _ptr(frontier) if n_in else None, n_in, _ptr(out),
                                      out.numel(), C.byref(n_out)), "grx_filter")
@@ -467,6 +498,7 @@ def uniquify(ctx: Context, frontier, algorithm: UniquifyAlgorithm = UniquifyAlgo
     work = frontier.clone()
     out = torch.empty(max(n_in, 1), dtype=torch.int32, device=f"cuda:{ctx.device}")
     n_out = C.c_int64()
+    ctx.after_torch()
     _check(load_library().grx_uniquify(ctx._h, int(algorithm), int(best_effort),
                                        _ptr(work) if n_in else None, n_in, _ptr(out), out.numel(),
                                        C.byref(n_out)), "grx_uniquify")

@@ -95,13 +95,15 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
 
 
 def build_cpp_tests(force: bool = False) -> list:
-    """tests/cpp/engine_tests (+ a build with the schedule override macro): C++-level checks of
-    the header surface, run by the GPU test suite."""
-    src = os.path.join(ROOT, "tests", "cpp", "engine_tests.hip")
+    """tests/cpp/engine_tests (+ a build with the schedule override macro) and boundary_tests:
+    C++-level checks of the header surface, run by the GPU test suite."""
     outs = []
-    hdr_time = max(_newest(_headers()), os.path.getmtime(src))
     jobs = []
-    for name, defs in (("engine_tests", []), ("engine_tests_override", ["-DGRX_ADVANCE_LB_OVERRIDE=bucketing"])):
+    for name, source, defs in (("engine_tests", "engine_tests.hip", []),
+                               ("engine_tests_override", "engine_tests.hip", ["-DGRX_ADVANCE_LB_OVERRIDE=bucketing"]),
+                               ("boundary_tests", "boundary_tests.hip", [])):
+        src = os.path.join(ROOT, "tests", "cpp", source)
+        hdr_time = max(_newest(_headers()), os.path.getmtime(src))
         out = os.path.join(ROOT, "tests", "cpp", name)
         outs.append(out)
         if force or not os.path.exists(out) or os.path.getmtime(out) < hdr_time:

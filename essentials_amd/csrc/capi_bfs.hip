@@ -18,6 +18,9 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
     return with_load_balance(o.load_balance, [&](auto lb_tag) -> int {
       constexpr auto lb = decltype(lb_tag)::value;
       using problem_type = clients::bfs_problem_t<graph_type>;
+      if (o.direction_optimized)
+        if (int rc = ensure_can_pull(ctx, g))
+          return rc;
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, source, d_distances, ctx->mc);

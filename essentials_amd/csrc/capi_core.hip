@@ -46,6 +46,51 @@ unsigned long long essentials_amd::reduce_max_degree(const int32_t* d_row_offset
   return md;
 }
 
+namespace {
+__global__ void __launch_bounds__(256)
+    count_differences_kernel(const int32_t* a, const int32_t* b, long long n, unsigned long long* out) {
+  unsigned long long local = 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    local += a[i] != b[i];
+  local = gunrock::hip::wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local)
+    atomicAdd(out, local);
+}
+}  // namespace
+
+int essentials_amd::ensure_can_pull(grx_context_s* ctx, grx_graph_s* g) {
+  if (g->in_edges || g->symmetry == grx_graph_s::symmetric)
+    return GRX_OK;
+  if (g->symmetry == grx_graph_s::symmetry_unknown) {
+    // the CSR is its own transpose iff its transpose (in-neighbours in ascending order) equals
+    // the CSR with every row sorted by column: compare offsets, then indices
+    auto& sc = ctx->single();
+    graph_type G = g->view();
+    auto T = graph::build::transpose(G, sc);
+    grx_graph_t sorted = nullptr;
+    int rc = grx_graph_sorted_rows(ctx, g, &sorted);
+    error::throw_if_exception(rc != GRX_OK, "symmetry check: sorting the rows failed");
+    std::unique_ptr<grx_graph_s> owner(sorted);
+    hip::buffer_t<unsigned long long> diff(1);
+    GRX_HIP_CHECK(hipMemsetAsync(diff.data(), 0, 8, sc.stream()));
+    const unsigned grid = (unsigned)sc.compute_units() * 8;
+    count_differences_kernel<<<grid, 256, 0, sc.stream()>>>(T.offsets.data(), g->d_ap,
+                                                            (long long)g->n_rows + 1, diff.data());
+    if (g->nnz)
+      count_differences_kernel<<<grid, 256, 0, sc.stream()>>>(T.indices.data(), sorted->d_aj,
+                                                              (long long)g->nnz, diff.data());
+    GRX_HIP_CHECK(hipGetLastError());
+    unsigned long long d = 0;
+    GRX_HIP_CHECK(hipMemcpyAsync(&d, diff.data(), 8, hipMemcpyDeviceToHost, sc.stream()));
+    sc.synchronize();
+    g->symmetry = d == 0 ? grx_graph_s::symmetric : grx_graph_s::asymmetric;
+  }
+  if (g->symmetry == grx_graph_s::asymmetric)
+    return unsupported("pull traversal of a DIRECTED graph needs its in-edges: call "
+                       "grx_graph_build_in_edges first (the CSR is not its own transpose)");
+  return GRX_OK;
+}
+
 extern "C" {
 
 int grx_abi_version(void) { return GRX_ABI_VERSION; }
@@ -91,6 +136,27 @@ int grx_context_synchronize(grx_context_t ctx) {
     return invalid("context is NULL");
   return guarded([&] {
     ctx->single().synchronize();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_context_wait_stream(grx_context_t ctx, void* other_stream) {
+  if (!ctx)
+    return invalid("context is NULL");
+  return guarded([&] {
+    auto& c = ctx->single();
+    if ((hipStream_t)other_stream == c.stream())
+      return (int)GRX_OK;
+    // device-side ordering only: nobody waits on the host
+    GRX_HIP_CHECK(hipEventRecord(c.event(), (hipStream_t)other_stream));
+    GRX_HIP_CHECK(hipStreamWaitEvent(c.stream(), c.event(), 0));
+    return (int)GRX_OK;
+  });
+}
+
+int grx_trim_cache(void) {
+  return guarded([&] {
+    hip::block_cache_t::instance().trim();
     return (int)GRX_OK;
   });
 }
@@ -148,9 +214,13 @@ int grx_graph_from_mtx(const char* path, grx_graph_t* out) {
     io::matrix_market_t<vertex_t, edge_t, weight_t> mm;
     format::csr_t<memory_space_t::host, vertex_t, edge_t, weight_t> csr;
     csr.from_coo(mm.load(path));
-    return grx_graph_from_host_csr(csr.number_of_rows, csr.number_of_columns, csr.number_of_nonzeros,
-                                   csr.row_offsets.data(), csr.column_indices.data(),
-                                   csr.nonzero_values.data(), out);
+    int rc = grx_graph_from_host_csr(csr.number_of_rows, csr.number_of_columns, csr.number_of_nonzeros,
+                                     csr.row_offsets.data(), csr.column_indices.data(),
+                                     csr.nonzero_values.data(), out);
+    // a "symmetric" file is expanded to both directions by the loader: its own transpose
+    if (rc == GRX_OK && mm.scheme == io::symmetric)
+      (*out)->symmetry = grx_graph_s::symmetric;
+    return rc;
   });
 }
 

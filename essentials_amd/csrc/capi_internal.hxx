@@ -66,12 +66,25 @@ struct grx_context_s {
   gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
 };
 
+struct grx_graph_s;
 namespace essentials_amd {
 /// max over rows of (offsets[i + 1] - offsets[i]) of a device CSR; synchronous (capi_core.hip).
 unsigned long long reduce_max_degree(const int32_t* d_row_offsets, int32_t n_rows);
+/// A pull traversal is about to walk `g`'s in-edges: a graph without an attached transpose must
+/// be its own transpose.  Verifies that once on the device when nobody has said (builds the
+/// transpose, compares it with the column-sorted CSR); GRX_ERR_UNSUPPORTED for a directed graph
+/// (capi_core.hip).  Call inside guarded().
+int ensure_can_pull(grx_context_s* ctx, grx_graph_s* g);
 }  // namespace essentials_amd
 
 struct grx_graph_s {
+  grx_graph_s() {
+    // a graph's arrays live long and have odd sizes: when the handle dies they go straight back to
+    // the device instead of being parked for reuse (hip::block_cache_t)
+    ap.set_parking(false);
+    aj.set_parking(false);
+    ax.set_parking(false);
+  }
   int32_t n_rows = 0, n_cols = 0;
   int64_t nnz = 0;
   // owning storage (empty for a view over caller memory)
@@ -86,6 +99,11 @@ struct grx_graph_s {
   // largest out-degree, reduced on first use (the CSR arrays of a handle do not change)
   mutable unsigned long long max_degree = 0;
   mutable bool max_degree_known = false;
+  // is the CSR its own transpose (an undirected graph)?  Known to the builders that symmetrise
+  // (R-MAT, symmetric Matrix Market files); otherwise verified on the device the first time a
+  // PULL traversal asks (essentials_amd::ensure_can_pull)
+  enum symmetry_t { symmetry_unknown = 0, symmetric = 1, asymmetric = 2 };
+  mutable int symmetry = symmetry_unknown;
 
   essentials_amd::graph_type view() const {
     using namespace gunrock;
@@ -98,9 +116,12 @@ struct grx_graph_s {
     }
     // never 0 ("unknown"): an edgeless graph reports 1, which only loosens a sizing bound
     G.properties.max_degree = max_degree ? max_degree : 1ull;
+    G.properties.symmetric = symmetry == symmetric;
     if (in_edges) {
       G.properties.directed = true;
       in_edges->attach_to(G);
+    } else if (symmetry == asymmetric) {
+      G.properties.directed = true;  // no in-edge view: G.can_pull() is false
     }
     return G;
   }

@@ -19,12 +19,13 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
       constexpr auto lb = decltype(lb_tag)::value;
       using problem_type = clients::pr_problem_t<graph_type>;
       using enactor_type = clients::pr_enactor_t<problem_type, lb>;
+      if (o.direction_optimized)
+        if (int rc = ensure_can_pull(ctx, g))
+          return rc;
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, alpha, tol, d_p, ctx->mc);
       problem.pull = o.direction_optimized != 0;
-      error::throw_if_exception(problem.pull && !G.can_pull(),
-                                "grx_pagerank: the pull form needs in-edges (grx_graph_build_in_edges)");
       problem.init();
       problem.reset();
       enactor_properties_t props;

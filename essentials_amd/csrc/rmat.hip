@@ -211,7 +211,10 @@ extern "C" int grx_graph_rmat(grx_context_t ctx, uint32_t scale, uint32_t edge_f
   if (!ctx || !out)
     return invalid("grx_graph_rmat: NULL argument");
   return guarded([&] {
-    *out = rmat_build(ctx->single(), scale, edge_factor, seed, weight_seed, symmetrize).release();
+    auto g = rmat_build(ctx->single(), scale, edge_factor, seed, weight_seed, symmetrize);
+    // the generator knows: symmetrised = its own transpose; raw pairs = a directed graph
+    g->symmetry = symmetrize ? grx_graph_s::symmetric : grx_graph_s::asymmetric;
+    *out = g.release();
     // the generator's sort buffers (16 B per slot: 32 GiB at scale 26) are of no use to the
     // operators: do not let them fill the frontier block cache
     hip::block_cache_t::instance().trim();

@@ -164,6 +164,7 @@ class HipKernels:
 
     def expand(self, op, labels, rnd, frontier, n_frontier, scratch, sent, send) -> int:
         n = C.c_int64()
+        self.ctx.after_torch()
         ea._check(self.lib.grx_partitioned_expand(
             self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), rnd,
             frontier.data_ptr() if n_frontier else None, n_frontier, scratch.data_ptr(),
@@ -173,6 +174,7 @@ class HipKernels:
 
     def admit(self, op, labels, stamp, rnd, recv, fmt, world, slot, rank, lo, hi, nxt):
         n_next = C.c_int64()
+        self.ctx.after_torch()
         ea._check(self.lib.grx_partitioned_admit(
             self.ctx._h, op, labels.data_ptr(), labels.numel(), stamp.data_ptr(), rnd,
             recv.data_ptr(), fmt, world, slot, rank, lo, hi, nxt.data_ptr(), nxt.numel(),
@@ -181,12 +183,14 @@ class HipKernels:
 
     def level_bitmap(self, depth, level, words) -> None:
         """words[ceil(V/64)] <- bit v = (depth[v] == level); enqueue-only."""
+        self.ctx.after_torch()
         ea._check(self.lib.grx_partitioned_level_bitmap(
             self.ctx._h, depth.data_ptr(), depth.numel(), level, words.data_ptr(), words.numel()),
             "grx_partitioned_level_bitmap")
 
     def pr_scatter(self, alpha, p, scale, compute_scale, partial, lo, hi) -> None:
         """grx_pagerank_partitioned_scatter: partial <- this rank's PageRank contributions."""
+        self.ctx.after_torch()
         ea._check(self.lib.grx_pagerank_partitioned_scatter(
             self.ctx._h, self.g._h, alpha, p.data_ptr(), scale.data_ptr(), int(compute_scale),
             partial.data_ptr(), lo, hi, C.byref(self.opts)), "grx_pagerank_partitioned_scatter")
@@ -195,6 +199,7 @@ class HipKernels:
              fcount, scratch, send, snapshot=None) -> None:
         """Fused, enqueue-only superstep (grx_partitioned_step): admit `recv` -> [snapshot the owned
         labels ->] advance -> pack."""
+        self.ctx.after_torch()
         ea._check(self.lib.grx_partitioned_step(
             self.ctx._h, self.g._h, C.byref(self.opts), op, labels.data_ptr(), stamp.data_ptr(),
             sent.data_ptr(), rnd, recv.data_ptr() if recv is not None else None, fmt, world, slot,
@@ -210,9 +215,14 @@ class PartitionedPageRank:
     rank applies the same update, so the replicas stay identical and the stop test
     (max |p - p_previous| < tol after >= 1 iteration, pr.hxx:155-178) needs no extra collective."""
 
-    def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int, device):
+    def __init__(self, kernels, dist, rank: int, world: int, n_global: int, lo: int, hi: int, device,
+                 stream=None):
+        """stream: the torch stream the engine context was created on (so that the scatter kernels,
+        torch's update arithmetic and the all-reduce are ordered by ONE stream); None: the wrappers
+        order the engine's stream after torch's before every call (HipKernels -> after_torch)."""
         import torch
         self.torch, self.k, self.dist = torch, kernels, dist
+        self.stream = stream
         self.rank, self.world, self.n, self.lo, self.hi = rank, world, n_global, lo, hi
         f32 = torch.float32
         self.scale = torch.zeros(n_global, dtype=f32, device=device)
@@ -231,6 +241,12 @@ class PartitionedPageRank:
 
     def run(self, p, alpha: float = 0.85, tol: float = 1e-6, max_iterations: int = 0) -> dict:
         """p: replica [V] float32, overwritten with the ranks."""
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                return self._run(p, alpha, tol, max_iterations)
+        return self._run(p, alpha, tol, max_iterations)
+
+    def _run(self, p, alpha, tol, max_iterations) -> dict:
         torch = self.torch
         p.fill_(1.0 / self.n)
         if p.is_cuda:

@@ -135,6 +135,19 @@ const char* grx_last_error(void);
 int grx_context_create(int device, void* stream, grx_context_t* out);
 int grx_context_destroy(grx_context_t ctx);
 int grx_context_synchronize(grx_context_t ctx);
+/* Order everything already enqueued on `other_stream` (a hipStream_t; NULL = the null stream)
+ * before the context's NEXT work, on the device (event record + stream wait, no host wait).  A
+ * context created without a stream runs on a private NON-BLOCKING stream, which is not ordered
+ * after the null stream or after any other: a host that fills operands on its own stream (torch
+ * tensor ops) calls this before handing them to an engine entry point.  Results need no such call:
+ * the entry points return after the context's stream has drained (except the enqueue-only
+ * grx_partitioned_step / grx_partitioned_level_bitmap, which are meant to share the host's stream). */
+int grx_context_wait_stream(grx_context_t ctx, void* other_stream);
+/* Return every device block the engine parked for reuse (frontier buffers of finished runs, up to
+ * 64 GiB per process) to the device.  The engine does so by itself before it reports an
+ * out-of-memory; a host that shares the device with another allocator calls this when THAT one
+ * runs short. */
+int grx_trim_cache(void);
 int grx_context_device_info(grx_context_t ctx, int32_t* compute_units, int32_t* wavefront_size,
                             int64_t* total_memory_bytes, char* name, size_t name_len);
 

@@ -21,20 +21,30 @@
 #include <thrust/transform.h>
 #include <thrust/transform_reduce.h>
 
-#include <gunrock/hip/runtime.hxx>
+// core (reference algorithms.hxx:17-18)
+#include <gunrock/memory.hxx>
+#include <gunrock/error.hxx>
 #include <gunrock/hip/context.hxx>
+#include <gunrock/hip/launch_box.hxx>
 
+// framework (:21)
 #include <gunrock/framework/framework.hxx>
 
+// utilities (:24-26)
 #include <gunrock/util/math.hxx>
 #include <gunrock/util/type_limits.hxx>
+#include <gunrock/util/print.hxx>
 #include <gunrock/util/compare.hxx>
 
-#include <gunrock/container/vector.hxx>
+// formats, loaders, graph, containers (:29-41)
 #include <gunrock/formats/formats.hxx>
 #include <gunrock/io/matrix_market.hxx>
+#include <gunrock/io/smtx.hxx>
+#include <gunrock/io/sample.hxx>
 #include <gunrock/graph/graph.hxx>
 #include <gunrock/graph/transpose.hxx>
+#include <gunrock/container/array.hxx>
+#include <gunrock/container/vector.hxx>
 
 namespace gunrock {
 using memory::memory_space_t;

@@ -754,20 +754,23 @@ void execute(graph_t& G,
   detail::clocked_t clock(context);
   const unsigned probe_grid = detail::grid_for(n_in, k::ADV_BLOCK, persistent);
   const unsigned long_grid = (unsigned)context.compute_units() * 4u;
+  // a separate in-edge view: the emitted vertices' OUT-degrees (the next push's work) come from
+  // the forward offsets; an undirected CSR is its own transpose and needs no second lookup
+  const auto* fwd = G.has_in_edges() ? G.get_row_offsets() : nullptr;
   if (rejected) {
     k::pull_probe_kernel<output_type, true><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
         Gin, op, input.data(), n_in, out_ptr, capacity, rejected->data(), long_queue,
-        (unsigned long long)n_in, counters);
+        (unsigned long long)n_in, counters, fwd);
     k::pull_long_kernel<output_type, true><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
         Gin, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, rejected->data(),
-        (unsigned long long)n_in, counters);
+        (unsigned long long)n_in, counters, fwd);
   } else {
     k::pull_probe_kernel<output_type, false><<<probe_grid, k::ADV_BLOCK, 0, context.stream()>>>(
         Gin, op, input.data(), n_in, out_ptr, capacity, (vertex_t*)nullptr, long_queue,
-        (unsigned long long)n_in, counters);
+        (unsigned long long)n_in, counters, fwd);
     k::pull_long_kernel<output_type, false><<<long_grid, k::ADV_BLOCK, 0, context.stream()>>>(
         Gin, op, long_queue, (unsigned long long)n_in, out_ptr, capacity, (vertex_t*)nullptr, 0ull,
-        counters);
+        counters, fwd);
   }
   GRX_HIP_CHECK(hipGetLastError());
   clock.stop();

@@ -30,6 +30,9 @@ using memory::memory_space_t;
 struct graph_properties_t {
   bool directed{false};
   bool weighted{true};
+  /// true: the builder KNOWS the CSR is its own transpose (informational; `directed` is what
+  /// can_pull() tests).
+  bool symmetric{false};
   /// Largest out-degree when the builder of the view knows it (0 = unknown).  Operators that
   /// need it otherwise reduce it once per context and remember it by (offsets pointer, |V|, |E|)
   /// -- which cannot tell apart two graphs built one after the other in the same memory, so

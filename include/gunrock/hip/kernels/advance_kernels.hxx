@@ -958,7 +958,11 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                       vertex_t* __restrict__ rejected,
                       resume_t<vertex_t>* long_queue,
                       unsigned long long long_capacity,
-                      unsigned long long* counters) {
+                      unsigned long long* counters,
+                      const typename graph_t::edge_type* __restrict__ forward_offsets = nullptr) {
+  // forward_offsets: row offsets of the FORWARD graph when G is a separate in-edge view (a
+  // directed graph with an attached transpose).  The work hint left on the output frontier is the
+  // sum of OUT-degrees -- what the next push advance expands -- not of the in-degrees walked here.
   using edge_t = typename graph_t::edge_type;
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
@@ -1016,7 +1020,7 @@ __global__ void __launch_bounds__(ADV_BLOCK)
     if constexpr (HAS_OUT) {
       unsigned dn = 0;
       if (hit)
-        dn = (unsigned)deg;
+        dn = forward_offsets ? (unsigned)(forward_offsets[u + 1] - forward_offsets[u]) : (unsigned)deg;
       wq.push(hit, u, dn, output, capacity, counters);
     }
     if constexpr (REJECTS) {
@@ -1041,7 +1045,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                      std::size_t capacity,
                      vertex_t* __restrict__ rejected,
                      unsigned long long rejected_capacity,
-                     unsigned long long* counters) {
+                     unsigned long long* counters,
+                     const typename graph_t::edge_type* __restrict__ forward_offsets = nullptr) {
   using edge_t = typename graph_t::edge_type;
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
@@ -1079,7 +1084,10 @@ __global__ void __launch_bounds__(ADV_BLOCK)
     }
     if constexpr (HAS_OUT) {
       // lane 0 speaks for the wavefront
-      wq.push(found && lane == 0, u, found ? (unsigned)deg : 0u, output, capacity, counters);
+      unsigned dn = 0;
+      if (found && lane == 0)
+        dn = forward_offsets ? (unsigned)(forward_offsets[u + 1] - forward_offsets[u]) : (unsigned)deg;
+      wq.push(found && lane == 0, u, dn, output, capacity, counters);
     }
     if constexpr (REJECTS)
       rq.push(!found && lane == 0, u, 0u, rejected, (std::size_t)rejected_capacity, counters);

@@ -58,14 +58,30 @@ namespace memory {
 
 enum memory_space_t { device, host };
 
+namespace detail {
+/// Hook the device block cache (hip::block_cache_t, below) installs: frees everything it parks.
+inline void (*&trim_hook())() {
+  static void (*hook)() = nullptr;
+  return hook;
+}
+}  // namespace detail
+
 template <typename type_t>
 inline type_t* allocate(std::size_t bytes, memory_space_t space = memory_space_t::device) {
   void* p = nullptr;
   if (bytes) {
-    if (space == memory_space_t::device)
-      GRX_HIP_CHECK(hipMalloc(&p, bytes));
-    else
+    if (space == memory_space_t::device) {
+      hipError_t st = hipMalloc(&p, bytes);
+      if (st == hipErrorOutOfMemory && detail::trim_hook()) {
+        // blocks parked for reuse are the engine's to give back before anybody sees an OOM
+        (void)hipGetLastError();
+        detail::trim_hook()();
+        st = hipMalloc(&p, bytes);
+      }
+      GRX_HIP_CHECK(st);
+    } else {
       GRX_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    }
   }
   return reinterpret_cast<type_t*>(p);
 }
@@ -87,14 +103,18 @@ __host__ __device__ inline type_t* raw_pointer_cast(type_t* p) {
 
 }  // namespace memory
 
+using memory::memory_space_t;  // spelt unqualified by harnesses and unit tests (unittests/io/smtx.cuh:26)
+
 namespace hip {
 
 /**
  * @brief Process-wide cache of large device blocks.  An enactor reserves two frontiers of
  * 1.5 * max(|E|,|V|) elements (reference framework/enactor.hxx:181-192) and frees them when the
  * run ends; hipFree costs ~0.2 ms and synchronises the device, which is 20 % of an RMAT-22 BFS.
- * Blocks of >= 1 MiB are therefore parked here by exact size and handed back to the next run.
- * At most `limit_bytes` are parked; beyond that blocks are really freed.  Thread-safe.
+ * Blocks of >= 1 MiB are therefore parked here, keyed by (device, exact size), and handed back to
+ * the next run ON THAT DEVICE.  At most `limit_bytes` are parked; beyond that blocks are really
+ * freed; memory::allocate trims the cache and retries before it reports an out-of-memory.
+ * Thread-safe.
  */
 class block_cache_t {
  public:
@@ -102,13 +122,15 @@ class block_cache_t {
     static block_cache_t cache;
     return cache;
   }
+  /// A parked block of exactly `bytes` that lives on the CURRENT device, or nullptr.
   void* take(std::size_t bytes) {
     if (bytes < min_bytes)
       return nullptr;
+    const int device = current_device();
     std::lock_guard<std::mutex> lock(mutex_);
     for (std::size_t i = 0; i < blocks_.size(); ++i) {
-      if (blocks_[i].second == bytes) {
-        void* p = blocks_[i].first;
+      if (blocks_[i].bytes == bytes && blocks_[i].device == device) {
+        void* p = blocks_[i].ptr;
         blocks_[i] = blocks_.back();
         blocks_.pop_back();
         parked_ -= bytes;
@@ -117,32 +139,52 @@ class block_cache_t {
     }
     return nullptr;
   }
-  /// Returns true when the block was parked (caller must not free it).
-  bool give(void* p, std::size_t bytes) {
+  /// Returns true when the block was parked (caller must not free it).  `device` = the device the
+  /// block was allocated on (a block is only ever handed back to an allocation on that device).
+  bool give(void* p, std::size_t bytes, int device) {
     if (bytes < min_bytes)
       return false;
     std::lock_guard<std::mutex> lock(mutex_);
     if (parked_ + bytes > limit_bytes)
       return false;
-    blocks_.emplace_back(p, bytes);
+    blocks_.push_back(block_t{p, bytes, device});
     parked_ += bytes;
     return true;
   }
+  /// Really free everything parked (all devices).  Also what memory::allocate calls before it
+  /// reports an out-of-memory, and what grx_trim_cache() exports for hosts that share the device
+  /// with another allocator (torch).
   void trim() {
     std::lock_guard<std::mutex> lock(mutex_);
     for (auto& b : blocks_)
-      (void)hipFree(b.first);
+      (void)hipFree(b.ptr);
     blocks_.clear();
     parked_ = 0;
+  }
+  std::size_t parked_bytes() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return parked_;
+  }
+  static int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
   }
   static constexpr std::size_t min_bytes = 1ull << 20;
   static constexpr std::size_t limit_bytes = 64ull << 30;  // 64 GiB of a 288 GB part (an RMAT-26
                                                            // enactor holds 2 x 12.9 GB of frontiers)
 
  private:
-  block_cache_t() = default;
+  block_cache_t() {
+    memory::detail::trim_hook() = [] { block_cache_t::instance().trim(); };
+  }
+  struct block_t {
+    void* ptr;
+    std::size_t bytes;
+    int device;
+  };
   std::mutex mutex_;
-  std::vector<std::pair<void*, std::size_t>> blocks_;
+  std::vector<block_t> blocks_;
   std::size_t parked_ = 0;
 };
 
@@ -160,17 +202,21 @@ class buffer_t {
   buffer_t(type_t* external, std::size_t capacity) : ptr_(external), cap_(capacity), owns_(false) {}
   buffer_t(const buffer_t&) = delete;
   buffer_t& operator=(const buffer_t&) = delete;
-  buffer_t(buffer_t&& o) noexcept : ptr_(o.ptr_), cap_(o.cap_), owns_(o.owns_) {
+  buffer_t(buffer_t&& o) noexcept
+      : ptr_(o.ptr_), cap_(o.cap_), owns_(o.owns_), park_(o.park_), device_(o.device_) {
     o.ptr_ = nullptr; o.cap_ = 0;
   }
   buffer_t& operator=(buffer_t&& o) noexcept {
     if (this != &o) {
       release();
-      ptr_ = o.ptr_; cap_ = o.cap_; owns_ = o.owns_;
+      ptr_ = o.ptr_; cap_ = o.cap_; owns_ = o.owns_; park_ = o.park_; device_ = o.device_;
       o.ptr_ = nullptr; o.cap_ = 0;
     }
     return *this;
   }
+  /// false: storage goes straight back to the device when released (long-lived, odd-sized
+  /// arrays such as a graph's CSR would only clog the reuse cache).
+  void set_parking(bool park) { park_ = park; }
   ~buffer_t() { release(); }
 
   type_t* data() const { return ptr_; }
@@ -183,9 +229,11 @@ class buffer_t {
     error::throw_if_exception(!owns_, "caller-provided frontier storage is too small: need " +
                                           std::to_string(n) + " elements, have " +
                                           std::to_string(cap_));
-    type_t* fresh = reinterpret_cast<type_t*>(block_cache_t::instance().take(n * sizeof(type_t)));
+    type_t* fresh = park_ ? reinterpret_cast<type_t*>(block_cache_t::instance().take(n * sizeof(type_t)))
+                          : nullptr;
     if (!fresh)
       fresh = memory::allocate<type_t>(n * sizeof(type_t));
+    const int device = block_cache_t::current_device();
     if (ptr_ && keep) {
       GRX_HIP_CHECK(hipMemcpyAsync(fresh, ptr_, keep * sizeof(type_t), hipMemcpyDeviceToDevice, stream));
       GRX_HIP_CHECK(hipStreamSynchronize(stream));
@@ -193,10 +241,12 @@ class buffer_t {
     release();
     ptr_ = fresh;
     cap_ = n;
+    device_ = device;
   }
 
   void release() {
-    if (ptr_ && owns_ && !block_cache_t::instance().give(ptr_, cap_ * sizeof(type_t)))
+    if (ptr_ && owns_ &&
+        !(park_ && block_cache_t::instance().give(ptr_, cap_ * sizeof(type_t), device_)))
       (void)hipFree(ptr_);
     ptr_ = nullptr;
     cap_ = 0;
@@ -207,6 +257,8 @@ class buffer_t {
   type_t* ptr_ = nullptr;
   std::size_t cap_ = 0;
   bool owns_ = true;
+  bool park_ = true;
+  int device_ = 0;  // device the storage was allocated on
 };
 
 /**
@@ -248,6 +300,7 @@ class device_array_t {
     if (size_)
       GRX_HIP_CHECK(hipMemsetAsync(buf_.data(), 0, size_ * sizeof(type_t), stream));
   }
+  void set_parking(bool park) { buf_.set_parking(park); }
 
  private:
   buffer_t<type_t> buf_;

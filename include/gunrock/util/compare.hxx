@@ -1,7 +1,7 @@
 /**
  * @file compare.hxx
  * @brief util::compare(device, host, n[, error_op, verbose]) -> number of
- * mismatching elements (reference util/compare.hxx:37-56), and print::head.
+ * mismatching elements (reference util/compare.hxx:37-56).
  */
 #pragma once
 
@@ -42,15 +42,4 @@ std::size_t compare(const type_t* d_ptr, const type_t* h_ptr, const std::size_t 
 
 }  // namespace util
 
-namespace print {
-/// First `n` elements of a thrust-like vector or a device pointer range.
-template <typename vector_type>
-void head(vector_type& x, int n, std::string name = "") {
-  const std::size_t m = std::min<std::size_t>((std::size_t)n, x.size());
-  std::cout << name << "[:" << m << "] = ";
-  for (std::size_t i = 0; i < m; ++i)
-    std::cout << x[i] << " ";
-  std::cout << std::endl;
-}
-}  // namespace print
 }  // namespace gunrock

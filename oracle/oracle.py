@@ -45,11 +45,18 @@ def build(force: bool = False) -> None:
         os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "grx_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "libgrx_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir(os.environ.get("GRX_REFERENCE_ROOT", "/root/reference")) and (
-        force or not os.path.exists(_REF) or not os.path.exists(_REF_CLIENTS)
-        or not os.path.exists(_REF_CLIENTS.replace(".so", "_bucketing.so"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir(os.environ.get("GRX_REFERENCE_ROOT", "/root/reference")):
+        # the reference-built artefacts contain THIS engine's kernels (the reference's unchanged
+        # client headers and harnesses compiled against include/): stale once a header changed
+        import glob
+        root = os.path.dirname(_HERE)
+        inputs = glob.glob(os.path.join(root, "include", "**", "*.hxx"), recursive=True)
+        inputs += [os.path.join(_HERE, f) for f in ("ref_build.sh", "ref_clients_driver.cpp", "ref_driver.cpp")]
+        newest = max(os.path.getmtime(f) for f in inputs)
+        outputs = [_REF, _REF_CLIENTS, _REF_CLIENTS.replace(".so", "_bucketing.so")]
+        outputs += [os.path.join(_HERE, "_ref", "ref_" + a) for a in ("bfs", "sssp", "pr")]
+        if force or any(not os.path.exists(o) or os.path.getmtime(o) < newest for o in outputs):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
 class Oracle:

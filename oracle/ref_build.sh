@@ -38,4 +38,21 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
     -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
     "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients_bucketing.so"
   echo "ref_build: built $out/libgrx_ref_clients_bucketing.so"
+  # The reference's own example HARNESSES (examples/algorithms/{bfs,sssp,pr}/*.cu, what its CI
+  # runs: .github/workflows/ubuntu.yml:52-79), compiled in place and unmodified against this
+  # repository's include/.  The reference's include/ is searched AFTER ours and only its
+  # algorithms/{bfs,sssp,pr}.hxx may come from there: the dependency file is checked.
+  for a in bfs sssp pr; do
+    hipcc -x hip -std=c++17 -O3 --offload-arch=gfx950 \
+      -Wno-inconsistent-missing-override -Wno-unused-result \
+      -I "$repo/include" -idirafter "$ref/include" -MD -MF "$out/ref_$a.d" \
+      "$ref/examples/algorithms/$a/$a.cu" -o "$out/ref_$a"
+    foreign="$(grep -o "$ref/[^ ]*" "$out/ref_$a.d" | sort -u | \
+               grep -v -e "^$ref/examples/algorithms/$a/" -e "^$ref/include/gunrock/algorithms/$a.hxx\$" || true)"
+    if [ -n "$foreign" ]; then
+      echo "ref_build: harness $a pulled reference headers other than its algorithm header:"; echo "$foreign"; exit 1
+    fi
+    rm -f "$out/ref_$a.d"
+    echo "ref_build: built $out/ref_$a (harness)"
+  done
 fi
