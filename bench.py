@@ -168,7 +168,10 @@ def launch_ranks(n: int) -> int:
                 for q in live:
                     q.kill()
     reader.join(timeout=10)
-    sys.stdout.write("".join(chunks))
+    # stdout carries the ONE JSON line; anything else a library printed there (gloo's connection
+    # notice) goes to stderr
+    for line in "".join(chunks).splitlines(keepends=True):
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     return rc
 
@@ -279,10 +282,25 @@ def main():
                                f"(symmetrized, {runner.nnz} directed edges), {a.lb} advance, "
                                f"{world}xMI355X",
                    "algo": a.algo, "load_balance": a.lb, "vertices": runner.n, "edges": runner.nnz,
-                   "partitioning": "none" if world == 1 else f"1-D vertex ranges x{world}, RCCL all-gather"},
+                   "partitioning": "none" if world == 1 else f"1-D vertex ranges x{world}, "
+                                   "all-gather of the ranks' output frontiers between supersteps"},
         "roofline": roof,
         "detail": runner.detail(),
     }
+    if world > 1:
+        # what ran where: the process group torch sees, the transport the engine's C++ superstep
+        # loop used for the data path, one device per rank
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "device": device,
+                                      "name": torch.cuda.get_device_name(device),
+                                      "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))})
+        job = runner.ctx.job_info()
+        out["config"].update({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "exchange": runner.exchange, "engine_transport": job["backend"],
+                              "engine_world_size": job["world_size"], "devices": devs})
+        if runner.exchange_note:
+            out["config"]["exchange_note"] = runner.exchange_note
+        out["verify"] = runner.verify(sources[a.warmup])
     if world == 1 and "bfs" in a.algo:
         out["bfs_direction_optimized"] = runner.bfs_direction_optimized(
             sources[a.warmup:a.warmup + min(a.steps, 8)], lb)

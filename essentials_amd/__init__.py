@@ -7,13 +7,13 @@ groups from ``torch.distributed`` (RCCL).  There is NO CPU fallback: every call 
 HIP library and fails loudly when it is missing.
 """
 from .api import (  # noqa: F401
-    Context, Graph, Options, Stats, LoadBalance, FilterAlgorithm, UniquifyAlgorithm, EdgeOp,
+    Context, Graph, Options, Stats, PartitionedPlan, LoadBalance, FilterAlgorithm, UniquifyAlgorithm, EdgeOp,
     VertexOp, EngineError, bfs, sssp, pagerank, advance, filter, uniquify, library_path,
     INT_UNREACHED, FLT_UNREACHED,
 )
 
 __all__ = [
-    "Context", "Graph", "Options", "Stats", "LoadBalance", "FilterAlgorithm", "UniquifyAlgorithm",
+    "Context", "Graph", "Options", "Stats", "PartitionedPlan", "LoadBalance", "FilterAlgorithm", "UniquifyAlgorithm",
     "EdgeOp", "VertexOp", "EngineError", "bfs", "sssp", "pagerank", "advance", "filter",
     "uniquify", "library_path", "INT_UNREACHED", "FLT_UNREACHED",
 ]

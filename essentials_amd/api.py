@@ -81,6 +81,23 @@ class _Stats(C.Structure):
                 ("frontier_slots", C.c_int64 * 64), ("edges_expanded", C.c_int64)]
 
 
+class _PartitionedStats(C.Structure):
+    _fields_ = [("elapsed_ms", C.c_float), ("supersteps", C.c_int32), ("collectives", C.c_int32),
+                ("bitmap_supersteps", C.c_int32), ("allreduce_supersteps", C.c_int32),
+                ("iterations", C.c_int32), ("last_error", C.c_float),
+                ("pairs_exchanged", C.c_int64), ("bytes_sent", C.c_int64)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# collective callbacks of grx_context_attach_collectives
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32,
+                            C.c_void_p)
+UNIQUE_ID_BYTES = 128
+
+
 @dataclass
 class Options:
     load_balance: LoadBalance = LoadBalance.block_mapped
@@ -142,6 +159,20 @@ _SIGNATURES = {
     "grx_context_synchronize": (C.c_int, [_VP]),
     "grx_context_wait_stream": (C.c_int, [_VP, _VP]),
     "grx_trim_cache": (C.c_int, []),
+    "grx_copy_to_host": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "grx_copy_to_device": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "grx_job_unique_id": (C.c_int, [_VP]),
+    "grx_context_attach_rccl": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "grx_context_attach_collectives": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    "grx_context_detach": (C.c_int, [_VP]),
+    "grx_context_job_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p,
+                                       C.c_size_t]),
+    "grx_partitioned_create": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.POINTER(_Options),
+                                         C.c_int64, C.c_int64, C.c_int64, C.POINTER(_VP)]),
+    "grx_partitioned_destroy": (C.c_int, [_VP]),
+    "grx_partitioned_run": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, C.POINTER(_PartitionedStats)]),
+    "grx_partitioned_pagerank": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int32, _VP,
+                                           C.POINTER(_PartitionedStats)]),
     "grx_context_device_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]),
     "grx_graph_from_device_csr": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP,
@@ -280,6 +311,61 @@ class Context:
                "grx_measure_copy_bandwidth")
         return g.value
 
+    # -- multi-GPU job (gcuda::multi_context_t::attach_job) ---------------------------------
+    def attach_rccl(self, rank: int, world: int, unique_id: bytes) -> None:
+        """Join an RCCL job: ncclCommInitRank with the id rank 0 got from Context.unique_id().
+        Collective over all ranks."""
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        _check(load_library().grx_context_attach_rccl(self._h, rank, world, buf),
+               "grx_context_attach_rccl")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(load_library().grx_job_unique_id(buf), "grx_job_unique_id")
+        return buf.raw
+
+    def attach_collectives(self, rank: int, world: int, all_gather, all_reduce) -> None:
+        """Join a job whose collectives are host callbacks:
+        all_gather(d_send: int, d_recv: int, bytes_per_rank: int, stream: int) -> int (0 = ok) and
+        all_reduce(d_buffer: int, count: int, dtype: int, op: int, stream: int) -> int."""
+        def _ag(_user, send, recv, nbytes, stream):
+            try:
+                return int(all_gather(send, recv, nbytes, stream) or 0)
+            except Exception as e:   # an exception must not unwind through the C frames
+                print(f"[essentials_amd] all_gather callback failed: {e!r}", flush=True)
+                return -1
+
+        def _ar(_user, buf, count, dtype, op, stream):
+            try:
+                return int(all_reduce(buf, count, dtype, op, stream) or 0)
+            except Exception as e:
+                print(f"[essentials_amd] all_reduce callback failed: {e!r}", flush=True)
+                return -1
+        self._callbacks = (ALL_GATHER_FN(_ag), ALL_REDUCE_FN(_ar))   # keep them alive
+        _check(load_library().grx_context_attach_collectives(
+            self._h, rank, world, C.cast(self._callbacks[0], _VP), C.cast(self._callbacks[1], _VP),
+            None), "grx_context_attach_collectives")
+
+    def detach(self) -> None:
+        _check(load_library().grx_context_detach(self._h), "grx_context_detach")
+        self._callbacks = None
+
+    def job_info(self) -> dict:
+        r, w = C.c_int32(), C.c_int32()
+        name = C.create_string_buffer(32)
+        _check(load_library().grx_context_job_info(self._h, r, w, name, 32), "grx_context_job_info")
+        return {"rank": r.value, "world_size": w.value, "backend": name.value.decode()}
+
+    def copy_to_host(self, h_dst: np.ndarray, d_src: int) -> None:
+        _check(load_library().grx_copy_to_host(self._h, h_dst.ctypes.data, d_src, h_dst.nbytes),
+               "grx_copy_to_host")
+
+    def copy_to_device(self, d_dst: int, h_src: np.ndarray) -> None:
+        _check(load_library().grx_copy_to_device(self._h, d_dst, h_src.ctypes.data, h_src.nbytes),
+               "grx_copy_to_device")
+
     @staticmethod
     def trim_cache() -> None:
         """Return the device blocks the engine parked for reuse to the device (see
@@ -297,6 +383,48 @@ class Context:
     def close(self) -> None:
         if self._h:
             load_library().grx_context_destroy(self._h)
+            self._h = _VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PartitionedPlan:
+    """grx_partitioned_t: the persistent state of vertex-partitioned traversals on one rank and the
+    C++ superstep loop over it (grx_partitioned_run / grx_partitioned_pagerank).  The context must
+    already be attached to its job (Context.attach_rccl / attach_collectives)."""
+
+    def __init__(self, ctx: Context, local: "Graph", row_begin: int, row_end: int,
+                 options: Optional["Options"] = None, small_slot: int = 0, dense_threshold: int = 0,
+                 replica_threshold: int = 0):
+        self._h = _VP()
+        self.ctx, self.local = ctx, local     # keep both alive
+        o = (options or Options())._c()
+        _check(load_library().grx_partitioned_create(ctx._h, local._h, row_begin, row_end, C.byref(o),
+                                                     small_slot, dense_threshold, replica_threshold,
+                                                     C.byref(self._h)), "grx_partitioned_create")
+
+    def run(self, op: "EdgeOp", source: int, labels) -> dict:
+        """labels: replica [V] (int32 for BFS, float32 for SSSP), overwritten.  Collective."""
+        s = _PartitionedStats()
+        self.ctx.after_torch()
+        _check(load_library().grx_partitioned_run(self._h, int(op), source, _ptr(labels), C.byref(s)),
+               "grx_partitioned_run")
+        return s.as_dict()
+
+    def pagerank(self, p, alpha: float = 0.85, tol: float = 1e-6, max_iterations: int = 0) -> dict:
+        s = _PartitionedStats()
+        self.ctx.after_torch()
+        _check(load_library().grx_partitioned_pagerank(self._h, alpha, tol, max_iterations, _ptr(p),
+                                                       C.byref(s)), "grx_partitioned_pagerank")
+        return s.as_dict()
+
+    def close(self) -> None:
+        if self._h:
+            load_library().grx_partitioned_destroy(self._h)
             self._h = _VP()
 
     def __del__(self):

@@ -154,6 +154,30 @@ int grx_context_wait_stream(grx_context_t ctx, void* other_stream) {
   });
 }
 
+int grx_copy_to_host(grx_context_t ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!ctx || (bytes && (!h_dst || !d_src)))
+    return invalid("grx_copy_to_host: bad arguments");
+  return guarded([&] {
+    auto& c = ctx->single();
+    if (bytes)
+      GRX_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream()));
+    c.synchronize();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_copy_to_device(grx_context_t ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !h_src)))
+    return invalid("grx_copy_to_device: bad arguments");
+  return guarded([&] {
+    auto& c = ctx->single();
+    if (bytes)
+      GRX_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c.stream()));
+    c.synchronize();  // pageable source: the staging copy AND the DMA have finished
+    return (int)GRX_OK;
+  });
+}
+
 int grx_trim_cache(void) {
   return guarded([&] {
     hip::block_cache_t::instance().trim();

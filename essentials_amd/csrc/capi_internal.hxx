@@ -59,10 +59,7 @@ inline int unsupported(const char* why) {
 struct grx_context_s {
   std::shared_ptr<gunrock::gcuda::multi_context_t> mc;
   int device = 0;
-  void* comm = nullptr;  // ncclComm_t when attached to a job
   unsigned long long pending_sequence = 0;  // counters hand-off of an enqueue-only call
-  int rank = 0;
-  int world = 1;
   gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
 };
 

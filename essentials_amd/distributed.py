@@ -154,6 +154,64 @@ class SingleRunner:
 
 
 # --------------------------------------------------------------------------- multi GPU
+class HostStagedCollectives:
+    """The two collectives of a job as HOST callbacks over a torch.distributed process group whose
+    backend moves host memory (gloo): device -> host (grx_copy_to_host), the collective on CPU
+    tensors, host -> device.  What the test rigs attach with Context.attach_collectives so that the
+    C++ superstep loop (grx_partitioned_run) runs with several ranks sharing one GPU; production
+    attaches RCCL instead (attach_job)."""
+
+    _NP = {0: np.int32, 1: np.float32, 2: np.int64}
+
+    def __init__(self, ctx: ea.Context, dist):
+        import torch
+        self.torch, self.ctx, self.dist = torch, ctx, dist
+        self.world = dist.get_world_size()
+        self.calls = {"all_gather": 0, "all_reduce": 0}
+
+    def all_gather(self, d_send: int, d_recv: int, nbytes: int, stream: int) -> int:
+        torch = self.torch
+        self.calls["all_gather"] += 1
+        mine = np.empty(nbytes, np.uint8)
+        self.ctx.copy_to_host(mine, d_send)          # drains the engine's stream first
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(mine))
+        self.ctx.copy_to_device(d_recv, torch.cat(parts).numpy())
+        return 0
+
+    def all_reduce(self, d_buffer: int, count: int, dtype: int, op: int, stream: int) -> int:
+        torch = self.torch
+        self.calls["all_reduce"] += 1
+        h = np.empty(count, self._NP[dtype])
+        self.ctx.copy_to_host(h, d_buffer)
+        t = torch.from_numpy(h)
+        rop = {0: self.dist.ReduceOp.MIN, 1: self.dist.ReduceOp.SUM, 2: self.dist.ReduceOp.MAX}[op]
+        self.dist.all_reduce(t, op=rop)
+        self.ctx.copy_to_device(d_buffer, h)
+        return 0
+
+
+def attach_job(ctx: ea.Context, dist, transport: str | None = None) -> str:
+    """Attach `ctx` to the job `dist` (an initialised torch.distributed) describes.
+    transport "rccl": the engine's OWN RCCL communicator (ncclCommInitRank; rank 0's unique id
+    travels through the process group) -- the C++ loop then calls ncclAllGather / ncclAllReduce
+    itself; "hooks": host-staged callbacks over the process group.  Default: rccl when the group's
+    backend is nccl, hooks otherwise.  Returns the transport attached."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if transport is None:
+        transport = "rccl" if dist.get_backend() == "nccl" else "hooks"
+    if transport == "rccl":
+        box = [ea.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.attach_rccl(rank, world, box[0])
+    elif transport == "hooks":
+        ctx._collectives = HostStagedCollectives(ctx, dist)
+        ctx.attach_collectives(rank, world, ctx._collectives.all_gather, ctx._collectives.all_reduce)
+    else:
+        raise ValueError(f"unknown transport {transport!r}")
+    return transport
+
+
 class HipKernels:
     """The production local kernels: grx_partitioned_expand / grx_partitioned_admit."""
 
@@ -486,18 +544,28 @@ class PartitionedTraversal:
 
 
 class PartitionedRunner:
-    """bench.py's N > 1 runner: every rank builds the R-MAT graph, keeps its slice."""
+    """bench.py's N > 1 runner: every rank builds the R-MAT graph, keeps its slice.
+
+    exchange = "rccl"  (default on an nccl group) the C++ superstep loop, collectives issued by the
+                       engine on its own RCCL communicator (grx_partitioned_run);
+               "hooks" the same C++ loop over host-staged callbacks (gloo rigs sharing one GPU);
+               "torch" round 1's Python loop with torch.distributed collectives."""
 
     def __init__(self, ctx: ea.Context, dist, scale, edge_factor, seed, weight_seed,
-                 options: ea.Options | None = None):
+                 options: ea.Options | None = None, exchange: str | None = None):
         import torch
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if exchange is None:
+            exchange = os.environ.get("GRX_BENCH_EXCHANGE") or \
+                ("rccl" if dist.get_backend() == "nccl" else "hooks")
+        self.exchange = exchange
         # ONE stream for the engine's kernels, torch's tensor ops and the collectives: the fused
         # superstep needs no cross-stream waits
         self.stream = torch.cuda.Stream(device=ctx.device)
         self.ctx = ctx = ea.Context(ctx.device, stream=self.stream.cuda_stream)
         full = ea.Graph.rmat(ctx, scale, edge_factor, seed, weight_seed, True)
+        self._scale, self._edge_factor, self._seed, self._wseed = scale, edge_factor, seed, weight_seed
         self.n, self.nnz = full.n_rows, full.nnz
         self._host = None    # the CPU baseline leg runs at N = 1 only
         ap = full.offsets_to_host()
@@ -514,16 +582,76 @@ class PartitionedRunner:
         dev = f"cuda:{ctx.device}"
         self.depth = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.distance = torch.empty(self.n, dtype=torch.float32, device=dev)
-        fused = options is None or options.load_balance == ea.LoadBalance.block_mapped
-        with torch.cuda.stream(self.stream):
-            self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist, self.rank,
-                                             self.world, self.n, self.lo, self.hi, self.local.nnz,
-                                             dev, fused=fused, stream=self.stream)
+        self.plan = self.trav = None
+        self.exchange_note = None
+        if exchange in ("rccl", "hooks"):
+            # every rank must end up on the same path: agree on whether the attachment worked
+            ok, why = 1, ""
+            try:
+                attach_job(ctx, dist, exchange)
+                self.plan = ea.PartitionedPlan(ctx, self.local, self.lo, self.hi, options)
+            except Exception as e:   # e.g. ncclCommInitRank refused: keep the torch.distributed loop
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32,
+                                device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if self.plan is not None:
+                    self.plan.close()
+                    self.plan = None
+                try:
+                    ctx.detach()
+                except Exception:
+                    pass
+                self.exchange_note = f"'{exchange}' attachment failed on some rank ({why}); torch.distributed loop"
+                self.exchange = exchange = "torch"
+        if exchange == "torch":
+            fused = options is None or options.load_balance == ea.LoadBalance.block_mapped
+            with torch.cuda.stream(self.stream):
+                self.trav = PartitionedTraversal(HipKernels(ctx, self.local, options), dist,
+                                                 self.rank, self.world, self.n, self.lo, self.hi,
+                                                 self.local.nnz, dev, fused=fused, stream=self.stream)
         self._torch = torch
         self._deg_dev = torch.from_numpy(self._deg).to(dev)
         self._zero = torch.zeros((), dtype=torch.int64, device=dev)
         self._acc = self._zero.clone()
         self.last = {}
+
+    def verify(self, source: int) -> dict:
+        """Outside the timed region: do the ranks' label replicas agree after a partitioned BFS and
+        SSSP from `source`, and (rank 0 rebuilds the whole graph) do they equal the single-GPU
+        engine's labels bit for bit?  Collective."""
+        torch = self._torch
+        out = {"source": source}
+        sums = []
+        for op, labels in ((OP_BFS, self.depth), (OP_SSSP, self.distance)):
+            self._traverse(op, source, labels)
+            self.stream.synchronize()
+            bits = labels.view(torch.int32).to(torch.int64)
+            sums.append((int(bits.sum().item()), int((bits * (torch.arange(self.n, device=bits.device) % 1021 + 1)).sum().item())))
+        gathered = [None] * self.world
+        self.dist.all_gather_object(gathered, sums)
+        out["replicas_identical_across_ranks"] = all(g == gathered[0] for g in gathered)
+        if self.rank == 0:
+            try:
+                single = ea.Context(self.ctx.device)
+                full = ea.Graph.rmat(single, self._scale, self._edge_factor, self._seed, self._wseed, True)
+                d, _ = ea.bfs(single, full, source)
+                w, _ = ea.sssp(single, full, source)
+                out["bfs_equals_single_gpu"] = bool(torch.equal(d, self.depth))
+                out["sssp_bits_equal_single_gpu"] = bool(
+                    torch.equal(w.view(torch.int32), self.distance.view(torch.int32)))
+                full.close()
+                single.close()
+            except Exception as e:
+                out["single_gpu_check_error"] = repr(e)
+        return out
+
+    def _traverse(self, op: int, source: int, labels) -> dict:
+        if self.plan is not None:
+            with self._torch.cuda.stream(self.stream):
+                return self.plan.run(op, source, labels)
+        return self.trav.run(op, source, labels)
 
     def host_csr(self):
         return self._host
@@ -543,12 +671,12 @@ class PartitionedRunner:
     def bfs(self, source: int, opts=None) -> int:
         """Returns 0: the traversed-edge count accumulates on the device (no host read in the timed
         region); flush_edges() hands the total over."""
-        self.last["bfs"] = self.trav.run(OP_BFS, source, self.depth)
+        self.last["bfs"] = self._traverse(OP_BFS, source, self.depth)
         self._edges(self.depth, ea.INT_UNREACHED)
         return 0
 
     def sssp(self, source: int, opts=None) -> int:
-        self.last["sssp"] = self.trav.run(OP_SSSP, source, self.distance)
+        self.last["sssp"] = self._traverse(OP_SSSP, source, self.distance)
         self._edges(self.distance, ea.FLT_UNREACHED)
         return 0
 
@@ -559,7 +687,7 @@ class PartitionedRunner:
         return total
 
     def bfs_roofline(self, source: int, lb) -> dict:
-        st = self.trav.run(OP_BFS, source, self.depth)
+        st = self._traverse(OP_BFS, source, self.depth)
         edges = int(self._edges(self.depth, ea.INT_UNREACHED).item())
         self.flush_edges()
         reached = int((self.depth != ea.INT_UNREACHED).sum().item())
@@ -572,5 +700,6 @@ class PartitionedRunner:
                 "supersteps": st["supersteps"]}
 
     def detail(self) -> dict:
-        return {k: dict(v, rows_owned=self.hi - self.lo, local_edges=self.local.nnz)
+        return {k: dict(v, rows_owned=self.hi - self.lo, local_edges=self.local.nnz,
+                        exchange=self.exchange)
                 for k, v in self.last.items()}

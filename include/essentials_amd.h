@@ -143,6 +143,11 @@ int grx_context_synchronize(grx_context_t ctx);
  * the entry points return after the context's stream has drained (except the enqueue-only
  * grx_partitioned_step / grx_partitioned_level_bitmap, which are meant to share the host's stream). */
 int grx_context_wait_stream(grx_context_t ctx, void* other_stream);
+/* Plain copies between host and device memory ON THE CONTEXT'S STREAM, complete when the call
+ * returns (the stream is drained).  For bindings without a HIP runtime of their own -- e.g. a
+ * host-staged collective callback (grx_context_attach_collectives). */
+int grx_copy_to_host(grx_context_t ctx, void* h_dst, const void* d_src, size_t bytes);
+int grx_copy_to_device(grx_context_t ctx, void* d_dst, const void* h_src, size_t bytes);
 /* Return every device block the engine parked for reuse (frontier buffers of finished runs, up to
  * 64 GiB per process) to the device.  The engine does so by itself before it reports an
  * out-of-memory; a host that shares the device with another allocator calls this when THAT one
@@ -237,7 +242,8 @@ int grx_uniquify(grx_context_t ctx, int32_t algorithm, int32_t best_effort, int3
  *                            the owned, improved vertices to the next input frontier
  * Dense BFS supersteps (more finds than V/64) exchange per-rank LEVEL BITMAPS instead of pairs
  * (grx_partitioned_level_bitmap + recv_format GRX_RECV_LEVEL_BITMAP).
- * The host loop and the collective live in essentials_amd/distributed.py. */
+ * grx_partitioned_run (below) is the whole loop in C++ with the collectives issued directly on
+ * RCCL; the step-level entry points stay public for hosts that bring their own loop. */
 
 /* Rank-local slice of a replicated graph; split points balance EDGES (prefix of row offsets). */
 int grx_graph_partition(grx_graph_t full, int rank, int world_size, grx_graph_t* out,
@@ -312,6 +318,72 @@ int grx_pagerank_partitioned_scatter(grx_context_t ctx, grx_graph_t local, float
                                      const float* d_rank, float* d_scale, int32_t compute_scale,
                                      float* d_partial, int32_t row_begin, int32_t row_end,
                                      const grx_options* opt);
+
+/* ---- multi-GPU: the job, and the whole traversal as ONE call -------------------------------- */
+/* A context joins a job of `world_size` ranks (one process per GPU; this IS
+ * gcuda::multi_context_t::attach_job).  Two transports:
+ *   grx_context_attach_rccl         RCCL over xGMI (production): ncclCommInitRank with the 128-byte
+ *                                   id rank 0 obtained from grx_job_unique_id and handed to the
+ *                                   other ranks by any side channel; collective over all ranks.
+ *                                   ncclAllGather / ncclAllReduce are then issued by the C++
+ *                                   superstep loop on the context's own stream.
+ *   grx_context_attach_collectives  host callbacks with the same meaning (device pointers in,
+ *                                   device pointers out; the callback may stage through the host
+ *                                   but must have completed when it returns).  For transports
+ *                                   other than RCCL and for test rigs (ranks sharing one GPU). */
+#define GRX_UNIQUE_ID_BYTES 128
+typedef enum grx_collective_dtype { GRX_INT32 = 0, GRX_FLOAT32 = 1, GRX_INT64 = 2 } grx_collective_dtype;
+typedef enum grx_collective_op { GRX_MIN = 0, GRX_SUM = 1, GRX_MAX = 2 } grx_collective_op;
+typedef int (*grx_all_gather_fn)(void* user, const void* d_send, void* d_recv,
+                                 uint64_t bytes_per_rank, void* stream);
+typedef int (*grx_all_reduce_fn)(void* user, void* d_buffer, uint64_t count, int32_t dtype,
+                                 int32_t op, void* stream);
+int grx_job_unique_id(void* id128);
+int grx_context_attach_rccl(grx_context_t ctx, int rank, int world_size, const void* id128);
+int grx_context_attach_collectives(grx_context_t ctx, int rank, int world_size,
+                                   grx_all_gather_fn all_gather, grx_all_reduce_fn all_reduce,
+                                   void* user);
+int grx_context_detach(grx_context_t ctx);
+/* backend: "single" (no job), "rccl" or "hooks". */
+int grx_context_job_info(grx_context_t ctx, int32_t* rank, int32_t* world_size, char* backend,
+                         size_t backend_len);
+
+/* A partitioned traversal's persistent state: the rank's slice, its owned range and every buffer
+ * the supersteps need (frontier, raw output, send / receive slots, level bitmaps, stamps), all
+ * allocated once.  small_slot: int64 words per rank in the first all-gather of a superstep
+ * (0 = 32768, i.e. 256 KiB); dense_threshold / replica_threshold: finds on the busiest rank
+ * above which BFS exchanges level bitmaps / SSSP all-reduces the replicas (0 = V/64 and
+ * V/world_size; negative = never). */
+typedef struct grx_partitioned_s* grx_partitioned_t;
+typedef struct grx_partitioned_stats {
+  float elapsed_ms;             /* host wall time of the superstep loop (device drained)        */
+  int32_t supersteps;
+  int32_t collectives;          /* all-gathers + all-reduces issued by this rank                 */
+  int32_t bitmap_supersteps;    /* BFS supersteps that exchanged level bitmaps                   */
+  int32_t allreduce_supersteps; /* SSSP supersteps that all-reduced (MIN) the replicas           */
+  int32_t iterations;           /* PageRank: iterations                                          */
+  float last_error;             /* PageRank: max |p - p_previous| of the last iteration          */
+  int64_t pairs_exchanged;      /* finds of all ranks over the run                               */
+  int64_t bytes_sent;           /* payload bytes this rank contributed to collectives            */
+} grx_partitioned_stats;
+int grx_partitioned_create(grx_context_t ctx, grx_graph_t local, int32_t row_begin, int32_t row_end,
+                           const grx_options* opt, int64_t small_slot, int64_t dense_threshold,
+                           int64_t replica_threshold, grx_partitioned_t* out);
+int grx_partitioned_destroy(grx_partitioned_t plan);
+/* The whole BSP loop in C++ (what essentials_amd/distributed.py drove from Python in round 1):
+ * reset the replica and the stamps, then per superstep ONE enqueue-only grx_partitioned_step, the
+ * all-gather of the send slots on the SAME stream, one host wait on the gathered counts, and --
+ * by the busiest rank's count -- the level-bitmap all-gather (BFS), the replica all-reduce (SSSP)
+ * or a second, larger all-gather.  edge_op: GRX_OP_BFS (d_labels int32[V]) or GRX_OP_SSSP
+ * (float[V]); every rank passes the same source and gets the full label array.  Collective over
+ * the job the context is attached to (a context without a job runs it as a job of one). */
+int grx_partitioned_run(grx_partitioned_t plan, int32_t edge_op, int32_t source, void* d_labels,
+                        grx_partitioned_stats* stats);
+/* PageRank on the same plan: per iteration the local scatter (grx_pagerank_partitioned_scatter),
+ * ONE all-reduce (SUM) of V + 1 floats, the update and the stop test
+ * max |p - p_previous| < tol after >= 1 iteration (pr.hxx:155-178); max_iterations 0 = none. */
+int grx_partitioned_pagerank(grx_partitioned_t plan, float alpha, float tol, int32_t max_iterations,
+                             float* d_p, grx_partitioned_stats* stats);
 
 /* ---- measurement helpers ------------------------------------------------- */
 /* Streaming copy of `bytes` (16 B per lane) timed with events on the context stream:

@@ -51,6 +51,9 @@ class communicator_t {
   communicator_t& operator=(const communicator_t&) = delete;
   ~communicator_t() { detach(); }
 
+  /// A transport attached to a job of ONE rank is still used (the collectives then run through
+  /// RCCL / the callbacks with a single participant): the production call sequence can be
+  /// exercised on a one-GPU box.
   void attach(int rank, int world, collective_table_t table) {
     error::throw_if_exception(world < 1 || rank < 0 || rank >= world, "communicator: bad rank / world size");
     error::throw_if_exception(world > 1 && (!table.all_gather || !table.all_reduce),
@@ -83,7 +86,7 @@ class communicator_t {
   void all_gather(const void* d_send, void* d_recv, std::size_t bytes_per_rank, hipStream_t stream) {
     ++traffic_.all_gathers;
     traffic_.bytes_sent += bytes_per_rank;
-    if (world_ == 1) {  // a job of one: the "gather" is the rank's own slot
+    if (!table_.all_gather) {  // no transport attached (a job of one): the rank's own slot
       if (d_send != d_recv && bytes_per_rank)
         GRX_HIP_CHECK(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, stream));
       return;
@@ -97,7 +100,7 @@ class communicator_t {
                   hipStream_t stream) {
     ++traffic_.all_reduces;
     traffic_.bytes_sent += count * (dtype == collective_dtype_t::int64 ? 8 : 4);
-    if (world_ == 1)
+    if (!table_.all_reduce)  // no transport attached (a job of one)
       return;
     const int rc = table_.all_reduce(table_.state, d_buffer, count, (int)dtype, (int)op, stream);
     error::throw_if_exception(rc != 0, std::string("all_reduce failed on the '") + table_.name +

@@ -14,12 +14,13 @@
  *  - the timer records on the context's stream (the reference records on the
  *    null stream while work runs on a non-blocking stream);
  *  - multi-GPU is one process per GPU: a multi_context_t holds the local device's
- *    context plus {rank, world_size, communicator} of the RCCL job (the reference
+ *    context plus the communicator_t {rank, world_size, collectives} of the RCCL job (the reference
  *    only holds a vector of local contexts and never uses more than the first:
  *    framework/enactor.hxx:243-254).
  */
 #pragma once
 
+#include <gunrock/hip/communicator.hxx>
 #include <gunrock/hip/runtime.hxx>
 
 #include <cstdio>
@@ -343,19 +344,33 @@ class multi_context_t {
   }
 
   // --- process-per-GPU job attachment (RCCL over xGMI) ----------------------
-  void attach_job(int rank, int world_size, void* communicator) {
-    rank_ = rank;
-    world_ = world_size;
-    comm_ = communicator;
+  /// Join a job of `world_size` ranks (one process per GPU).  `table` is the collective transport:
+  /// rccl::make(rank, world, id, device) in production, host callbacks in the test rigs.  A rank
+  /// owns the contiguous vertex range it is given with set_owned_rows(); the graph it traverses is
+  /// its slice of the global graph (graph::build::partition / grx_graph_partition: global vertex
+  /// ids, rows outside the range empty).  With a job attached, enactor_t::enact() exchanges the
+  /// frontiers between supersteps (framework/partitioned.hxx).
+  void attach_job(int rank, int world_size, collective_table_t table) {
+    comm_.attach(rank, world_size, table);
   }
-  int rank() const { return rank_; }
-  int world_size() const { return world_; }
-  void* communicator() const { return comm_; }
+  void detach_job() { comm_.detach(); }
+  int rank() const { return comm_.rank(); }
+  int world_size() const { return comm_.world_size(); }
+  communicator_t& communicator() { return comm_; }
+
+  /// Vertex range [begin, end) this rank owns (the whole graph when no job is attached).
+  void set_owned_rows(long long begin, long long end) {
+    owned_begin_ = begin;
+    owned_end_ = end;
+  }
+  long long owned_begin() const { return owned_begin_; }
+  long long owned_end() const { return owned_end_; }
+  bool owns(long long v) const { return owned_end_ < 0 || (v >= owned_begin_ && v < owned_end_); }
 
  private:
-  int rank_ = 0;
-  int world_ = 1;
-  void* comm_ = nullptr;  // ncclComm_t, owned by whoever attached it
+  communicator_t comm_;
+  long long owned_begin_ = 0;
+  long long owned_end_ = -1;  // -1: everything
 };
 
 }  // namespace gcuda

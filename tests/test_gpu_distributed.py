@@ -98,6 +98,48 @@ def test_partitioned_pagerank_world1_matches_single(oracle):
     assert abs(float(p.sum()) - 1.0) < 1e-3
 
 
+def test_cpp_superstep_loop_on_rccl_job_of_one(oracle):
+    """grx_partitioned_run = the superstep loop in C++ with the collectives issued DIRECTLY on RCCL
+    (ncclCommInitRank / ncclAllGather / ncclAllReduce on the engine's stream).  A one-GPU box can
+    host one rank only (RCCL refuses two ranks on one device), so this is the production call
+    sequence with a single participant; several ranks run the same loop over host callbacks below."""
+    import torch
+    import essentials_amd as ea
+    ctx = ea.Context(0)
+    ctx.attach_rccl(0, 1, ea.Context.unique_id())
+    assert ctx.job_info() == {"rank": 0, "world_size": 1, "backend": "rccl"}
+    g = ea.Graph.rmat(ctx, 14, 16, 1, 7)
+    Ap, Aj, Ax = g.to_host()
+    n = g.n_rows
+    for small_slot, dense, replica in ((0, 0, 0), (16, -1, -1), (16, 8, 8)):
+        plan = ea.PartitionedPlan(ctx, g, 0, n, None, small_slot, dense, replica)
+        for s in (0, 7217):
+            depth = torch.empty(n, dtype=torch.int32, device="cuda")
+            st = plan.run(ea.EdgeOp.bfs, s, depth)
+            want, _ = oracle.bfs_heap(Ap, Aj, s)
+            assert (depth.cpu().numpy() == want).all(), (small_slot, dense, s)
+            assert (st["bitmap_supersteps"] > 0) == (dense == 8), st
+            assert st["collectives"] >= st["supersteps"] and st["bytes_sent"] > 0
+            dist_ = torch.empty(n, dtype=torch.float32, device="cuda")
+            st2 = plan.run(ea.EdgeOp.sssp, s, dist_)
+            wantw, _ = oracle.sssp_heap(Ap, Aj, Ax, s)
+            assert (dist_.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all()
+            assert (st2["allreduce_supersteps"] > 0) == (replica == 8), st2
+        plan.close()
+    # PageRank: scatter + ncclAllReduce(SUM) + update, all in the C++ loop
+    gd = ea.Graph.rmat(ctx, 13, 8, 3, 5, False)
+    Ap, Aj, Ax = gd.to_host()
+    want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    plan = ea.PartitionedPlan(ctx, gd, 0, gd.n_rows)
+    p = torch.empty(gd.n_rows, dtype=torch.float32, device="cuda")
+    st = plan.pagerank(p, 0.85, 1e-6)
+    assert abs(st["iterations"] - it) <= 1 and st["collectives"] == st["iterations"]
+    assert np.allclose(p.cpu().numpy(), want, rtol=2e-4, atol=1e-9)
+    plan.close()
+    ctx.detach()
+    assert ctx.job_info()["backend"] == "single"
+
+
 def _rank(rank, world, port, scale, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -147,6 +189,35 @@ def _rank(rank, world, port, scale, out_dir):
                 notes.append(f"sssp {s} {lb.name} {small_slot} {replica}")
             if replica == 32 and not st2.get("allreduce_supersteps"):
                 notes.append(f"sssp {s}: no all-reduce superstep {st2}")
+    # the same supersteps driven by the C++ loop (grx_partitioned_run), the collectives being host
+    # callbacks over this gloo group (production: RCCL, see the job-of-one test)
+    from essentials_amd.distributed import attach_job
+    cctx = ea.Context(0)
+    assert attach_job(cctx, dist) == "hooks"
+    assert cctx.job_info() == {"rank": rank, "world_size": world, "backend": "hooks"}
+    for small_slot, dense, replica in ((0, 0, 0), (64, -1, -1), (64, 32, 32)):
+        plan = ea.PartitionedPlan(cctx, local, lo.value, hi.value, None, small_slot, dense, replica)
+        for s in (0, 1830):
+            depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+            st1 = plan.run(ea.EdgeOp.bfs, s, depth)
+            want, _ = o.bfs_heap(Ap, Aj, s)
+            if not (depth.cpu().numpy() == want).all():
+                notes.append(f"c++ loop bfs {s} {small_slot} {dense}")
+            d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+            st2 = plan.run(ea.EdgeOp.sssp, s, d)
+            wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
+            if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
+                notes.append(f"c++ loop sssp {s} {small_slot} {replica}")
+            if dense == 32 and not (st1["bitmap_supersteps"] and st2["allreduce_supersteps"]):
+                notes.append(f"c++ loop: dense exchanges not taken {st1} {st2}")
+        plan.close()
+    plan = ea.PartitionedPlan(cctx, local, lo.value, hi.value)
+    p = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+    stp = plan.pagerank(p, 0.85, 1e-6)
+    want, it = o.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+    if not np.allclose(p.cpu().numpy(), want, rtol=2e-4, atol=1e-9) or abs(stp["iterations"] - it) > 1:
+        notes.append(f"c++ loop pagerank {stp} vs {it} iterations")
+    plan.close()
     # PageRank over the same slices (all-reduce of the partial vectors)
     p = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
     st = PartitionedPageRank(HipKernels(ctx, local), dist, rank, world, full.n_rows, lo.value,
@@ -163,6 +234,59 @@ def _rank(rank, world, port, scale, out_dir):
 def test_partitioned_two_ranks_share_one_gpu(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_rank, args=(world, _free_port(), 12, str(tmp_path)), nprocs=world, join=True)
+    names = sorted(os.listdir(tmp_path))
+    notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}
+    assert names == [f"rank{r}.ok" for r in range(world)], notes
+
+
+def _rank_large(rank, world, port, scale, out_dir):
+    """BASELINE configs[4]'s shape at the largest scale three ranks sharing ONE GPU finish inside
+    the test timeout: the C++ superstep loop over gloo callbacks against the single-GPU engine."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import essentials_amd as ea
+    from essentials_amd import api
+    from essentials_amd.distributed import attach_job
+    torch.cuda.set_device(0)
+    ctx = ea.Context(0)
+    full = ea.Graph.rmat(ctx, scale, 16, 1, 7)
+    h, lo, hi = api._VP(), C.c_int32(), C.c_int32()
+    api._check(api.load_library().grx_graph_partition(full._h, rank, world, C.byref(h), C.byref(lo),
+                                                      C.byref(hi)), "partition")
+    local = ea.Graph(h)
+    attach_job(ctx, dist)
+    plan = ea.PartitionedPlan(ctx, local, lo.value, hi.value)
+    notes = []
+    single = ea.Context(0)
+    for s in (0, 12345):
+        want_d, _ = ea.bfs(single, full, s)
+        want_w, _ = ea.sssp(single, full, s)
+        depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+        st = plan.run(ea.EdgeOp.bfs, s, depth)
+        w = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+        st2 = plan.run(ea.EdgeOp.sssp, s, w)
+        if not torch.equal(depth, want_d):
+            notes.append(f"bfs {s}: {int((depth != want_d).sum())} depths differ {st}")
+        if not torch.equal(w.view(torch.int32), want_w.view(torch.int32)):
+            notes.append(f"sssp {s}: distances differ {st2}")
+        if rank == 0:
+            print(f"scale {scale} x{world} source {s}: bfs {st['supersteps']} supersteps "
+                  f"({st['bitmap_supersteps']} bitmap) {st['elapsed_ms']:.1f} ms; sssp "
+                  f"{st2['supersteps']} supersteps ({st2['allreduce_supersteps']} all-reduce) "
+                  f"{st2['elapsed_ms']:.1f} ms", flush=True)
+    open(os.path.join(out_dir, f"rank{rank}." + ("bad" if notes else "ok")), "w").write(str(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_cpp_loop_three_ranks_rmat20(tmp_path):
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_rank_large, args=(world, _free_port(), 20, str(tmp_path)), nprocs=world, join=True)
     names = sorted(os.listdir(tmp_path))
     notes = {f: open(os.path.join(tmp_path, f)).read() for f in names}
     assert names == [f"rank{r}.ok" for r in range(world)], notes
