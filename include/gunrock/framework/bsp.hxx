@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <gunrock/framework/frontier.hxx>
+#include <gunrock/framework/partitioned.hxx>
 #include <gunrock/graph/graph.hxx>
 #include <gunrock/hip/context.hxx>
 
@@ -121,8 +122,12 @@ struct enactor_t {
     inactive_frontier = &frontiers[buffer_selector ^ 1];
   }
 
-  /// Run to convergence; returns the milliseconds spent in the loop.
+  /// Run to convergence; returns the milliseconds spent in the loop.  With a job attached to the
+  /// context (one process per GPU) the ranks exchange their frontiers after every loop():
+  /// framework/partitioned.hxx.
   float enact() {
+    if (context->communicator().attached())
+      return enact_partitioned();
     auto single_context = context->get_context(0);
     prepare_frontier(get_input_frontier(), *context);
     auto& timer = single_context->timer();
@@ -134,6 +139,42 @@ struct enactor_t {
     finalize(*context);
     return timer.end();
   }
+
+  /// enact() of one rank of a vertex-partitioned job.  The client's loop() runs unchanged on the
+  /// rank's slice; what it discovered is exchanged and the owned part becomes the next input
+  /// frontier.  Convergence = no rank discovered anything (is_converged() is a LOCAL test and is
+  /// not consulted: a rank whose own frontier is empty must keep taking part in the collectives).
+  float enact_partitioned() {
+    using traits = partitioned::exchange_traits<algorithm_problem_t>;
+    if constexpr (!traits::enabled || frontier_kind != frontier::frontier_kind_t::vertex_frontier) {
+      error::throw_if_exception(true,
+                                "this problem declares no replica combiner (partitioned::exchange_traits): "
+                                "it runs as independent replicas only, not vertex-partitioned");
+      return 0.0f;
+    } else {
+      auto single_context = context->get_context(0);
+      error::throw_if_exception(properties.self_manage_frontiers,
+                                "a partitioned run needs the enactor's frontiers");
+      const std::size_t n = (std::size_t)problem->get_graph().get_number_of_vertices();
+      prepare_frontier(get_input_frontier(), *context);
+      partitioned::keep_owned(*get_input_frontier(), *context);
+      auto& timer = single_context->timer();
+      timer.begin();
+      for (;;) {
+        loop(*context);  // advance (+ filter): the input frontier now holds this rank's finds
+        ++iteration;
+        const unsigned long long found = partitioned::exchange(
+            *get_input_frontier(), *get_output_frontier(), traits::labels(*problem), n,
+            exchange_state, *context);
+        swap_frontier_buffers();
+        if (found == 0)
+          break;
+      }
+      finalize(*context);
+      return timer.end();
+    }
+  }
+  partitioned::exchange_state_t exchange_state;
 
   virtual void loop(gcuda::multi_context_t& context) = 0;
   virtual void prepare_frontier(frontier_t*, gcuda::multi_context_t&) {}

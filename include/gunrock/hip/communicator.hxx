@@ -73,6 +73,8 @@ class communicator_t {
 
   int rank() const { return rank_; }
   int world_size() const { return world_; }
+  /// A job is attached (possibly of one rank): enactors exchange frontiers between supersteps.
+  bool attached() const { return table_.all_gather != nullptr; }
   const char* backend() const { return table_.name; }
   bool stream_ordered() const { return table_.stream_ordered; }
 

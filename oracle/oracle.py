@@ -306,6 +306,33 @@ class RefClients:
         L.refc_pr.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_float, C.c_float, vp,
                               C.POINTER(C.c_float)]
 
+        job = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_float), C.c_int, C.c_int,
+               C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        if hasattr(L, "refc_bfs_job"):
+            L.refc_bfs_job.argtypes = job
+            L.refc_sssp_job.argtypes = job
+            L.refc_pr_job_refused.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp]
+
+    def run_job(self, algo, ap, aj, ax, source, out, rank, world, lo, hi, unique_id=None,
+                all_gather=None, all_reduce=None):
+        """bfs.hxx / sssp.hxx unchanged as one rank of a vertex-partitioned job.  ap/aj/ax = the
+        rank's slice.  unique_id: 128 bytes -> RCCL; else all_gather / all_reduce = ctypes callbacks
+        (essentials_amd.api.ALL_GATHER_FN / ALL_REDUCE_FN)."""
+        ms = C.c_float()
+        fn = self.L.refc_bfs_job if algo == "bfs" else self.L.refc_sssp_job
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        rc = fn(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(), ax.data_ptr(), source,
+                out.data_ptr(), ms, rank, world, lo, hi, 1 if unique_id is not None else 0, idbuf,
+                C.cast(all_gather, C.c_void_p) if all_gather else None,
+                C.cast(all_reduce, C.c_void_p) if all_reduce else None)
+        assert rc == 0, f"{algo} job failed"
+        return ms.value
+
+    def pr_job_refused(self, ap, aj, ax, p, unique_id) -> bool:
+        idbuf = C.create_string_buffer(unique_id, 128)
+        return self.L.refc_pr_job_refused(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(),
+                                          ax.data_ptr(), p.data_ptr(), idbuf) == 1
+
     def bfs(self, ap, aj, ax, source, out):
         ms = C.c_float()
         rc = self.L.refc_bfs(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(), ax.data_ptr(),

@@ -26,7 +26,7 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
     -DGRX_REF_BFS_HXX="\"$ref/include/gunrock/algorithms/bfs.hxx\"" \
     -DGRX_REF_SSSP_HXX="\"$ref/include/gunrock/algorithms/sssp.hxx\"" \
     -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
-    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients.so"
+    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients.so" -L/opt/rocm/lib -lrccl
   echo "ref_build: built $out/libgrx_ref_clients.so"
   # BASELINE config 3: the unchanged sssp.hxx (which spells block_mapped, sssp.hxx:139) run with
   # the bucketing schedule through the documented compile-time override
@@ -36,7 +36,7 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
     -DGRX_REF_BFS_HXX="\"$ref/include/gunrock/algorithms/bfs.hxx\"" \
     -DGRX_REF_SSSP_HXX="\"$ref/include/gunrock/algorithms/sssp.hxx\"" \
     -DGRX_REF_PR_HXX="\"$ref/include/gunrock/algorithms/pr.hxx\"" \
-    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients_bucketing.so"
+    "$here/ref_clients_driver.cpp" -o "$out/libgrx_ref_clients_bucketing.so" -L/opt/rocm/lib -lrccl
   echo "ref_build: built $out/libgrx_ref_clients_bucketing.so"
   # The reference's own example HARNESSES (examples/algorithms/{bfs,sssp,pr}/*.cu, what its CI
   # runs: .github/workflows/ubuntu.yml:52-79), compiled in place and unmodified against this

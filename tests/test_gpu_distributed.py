@@ -211,6 +211,29 @@ def _rank(rank, world, port, scale, out_dir):
             if dense == 32 and not (st1["bitmap_supersteps"] and st2["allreduce_supersteps"]):
                 notes.append(f"c++ loop: dense exchanges not taken {st1} {st2}")
         plan.close()
+    # the REFERENCE's unchanged bfs.hxx / sssp.hxx as ranks of this job (oracle/_ref, when built):
+    # enactor_t::enact() exchanges the frontiers, the client headers are not touched
+    from oracle.oracle import RefClients
+    if RefClients.available() and hasattr(RefClients().L, "refc_bfs_job"):
+        rc_ = RefClients()
+        coll = cctx._collectives
+        ag = api.ALL_GATHER_FN(lambda u, a, b, nb, st: coll.all_gather(a, b, nb, st))
+        ar = api.ALL_REDUCE_FN(lambda u, b, c, d, o_, st: coll.all_reduce(b, c, d, o_, st))
+        lap, laj, lax = local.to_host()
+        tap, taj, tax = (torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (lap, laj, lax))
+        for s in (0, 1830):
+            depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+            rc_.run_job("bfs", tap, taj, tax, s, depth, rank, world, lo.value, hi.value,
+                        all_gather=ag, all_reduce=ar)
+            want, _ = o.bfs_heap(Ap, Aj, s)
+            if not (depth.cpu().numpy() == want).all():
+                notes.append(f"reference bfs.hxx partitioned, source {s}")
+            d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+            rc_.run_job("sssp", tap, taj, tax, s, d, rank, world, lo.value, hi.value,
+                        all_gather=ag, all_reduce=ar)
+            wantw, _ = o.sssp_heap(Ap, Aj, Ax, s)
+            if not (d.cpu().numpy().view(np.uint32) == wantw.view(np.uint32)).all():
+                notes.append(f"reference sssp.hxx partitioned, source {s}")
     plan = ea.PartitionedPlan(cctx, local, lo.value, hi.value)
     p = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
     stp = plan.pagerank(p, 0.85, 1e-6)

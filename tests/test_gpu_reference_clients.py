@@ -127,3 +127,31 @@ def test_reference_example_harness(algo, oracle):
     got = [float(x) for x in gpu.split("=")[1].split()]
     want = (oracle.bfs_heap(Ap, Aj, 0)[0] if algo == "bfs" else oracle.sssp_heap(Ap, Aj, Ax, 0)[0])
     assert got == [float(x) for x in want[:len(got)]]
+
+
+def test_reference_headers_as_a_partitioned_job_of_one_on_rccl(refc, oracle, golden):
+    """bfs.hxx / sssp.hxx UNCHANGED with the context attached to an RCCL job: enactor_t::enact()
+    exchanges the frontier between supersteps (framework/partitioned.hxx; the combiner of
+    `result.distances` is declared outside the client headers).  One GPU hosts one RCCL rank, so
+    this is the production call sequence (ncclCommInitRank, ncclAllGather on the engine's stream)
+    with a single participant; several ranks run it over host callbacks in test_gpu_distributed.
+    pr.hxx declares no combiner: a partitioned run is refused ("replicas only")."""
+    import torch
+    import essentials_amd as ea
+    if not hasattr(refc.L, "refc_bfs_job"):
+        pytest.skip("libgrx_ref_clients.so predates the job entry points")
+    for name in ("chesapeake", "sample4x4", "rmat10_w7", "rmat14_w0", "rmat10_directed"):
+        g = golden[name]
+        Ap, Aj, Ax = golden_graph(oracle, g)
+        ap, aj, ax = dev(Ap), dev(Aj), dev(Ax)
+        n = len(Ap) - 1
+        for run in g["runs"]:
+            d = torch.empty(n, dtype=torch.int32, device="cuda")
+            refc.run_job("bfs", ap, aj, ax, run["source"], d, 0, 1, 0, n, unique_id=ea.Context.unique_id())
+            assert sha(d.cpu().numpy()) == run["bfs_sha256"], (name, run["source"])
+            w = torch.empty(n, dtype=torch.float32, device="cuda")
+            refc.run_job("sssp", ap, aj, ax, run["source"], w, 0, 1, 0, n, unique_id=ea.Context.unique_id())
+            assert sha(w.cpu().numpy().view(np.uint32)) == run["sssp_bits_sha256"], (name, run["source"])
+    n, Ap, Aj, Ax = oracle.rmat_csr(9, 8, 3, 0, False)
+    p = torch.empty(n, dtype=torch.float32, device="cuda")
+    assert refc.pr_job_refused(dev(Ap), dev(Aj), dev(Ax), p, ea.Context.unique_id())
