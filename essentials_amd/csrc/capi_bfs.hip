@@ -55,12 +55,9 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
         stats->levels_recorded = problem.log.levels < 64 ? problem.log.levels : 64;
         for (int i = 0; i < stats->levels_recorded; ++i)
           stats->frontier_slots[i] = problem.log.input_slots[i];
-        {  // the first frontier ({source}) carries no work hint: add the source's own degree
-          int32_t row[2] = {0, 0};
-          GRX_HIP_CHECK(hipMemcpy(row, g->d_ap + source, sizeof row, hipMemcpyDeviceToHost));
-          stats->edges_expanded = problem.log.edges_expanded + (row[1] - row[0]);
-        }
-        reach_stats(g, d_distances, INT32_MAX, ctx->single(), stats);
+        // the first frontier ({source}) carries no work hint: add the source's own degree
+        stats->edges_expanded =
+            problem.log.edges_expanded + reach_stats(g, d_distances, (int32_t)INT32_MAX, source, ctx->single(), stats);
       }
       return (int)GRX_OK;
     });

@@ -4,6 +4,7 @@
  */
 #pragma once
 
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <memory>
@@ -166,26 +167,58 @@ int with_load_balance(int lb, F&& f) {
   }
 }
 
-/// vertices_reached / edges_traversed from a label array (outside the timed region).
+/// One pass over the labels: reached vertices, the sum of their out-degrees and the source's own
+/// degree land in three of the context's device counters (zero between operators).
 template <typename label_t>
-void reach_stats(grx_graph_s* g, const label_t* d_labels, label_t unreached,
-                 gcuda::standard_context_t& ctx, grx_stats* stats) {
+__global__ void __launch_bounds__(256)
+    reach_stats_kernel(const label_t* labels, label_t unreached, const int32_t* ap, int64_t n,
+                       int32_t source, unsigned long long* counters) {
+  __shared__ unsigned long long s_v[256 / gunrock::hip::wave_size], s_e[256 / gunrock::hip::wave_size];
+  unsigned long long v = 0, e = 0;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (labels[i] != unreached) {
+      ++v;
+      e += (unsigned long long)(ap[i + 1] - ap[i]);
+    }
+  }
+  v = gunrock::hip::wave_sum(v);
+  e = gunrock::hip::wave_sum(e);
+  if ((threadIdx.x & 63) == 0) {
+    s_v[threadIdx.x / gunrock::hip::wave_size] = v;
+    s_e[threadIdx.x / gunrock::hip::wave_size] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tv = 0, te = 0;
+    for (int k = 0; k < 256 / gunrock::hip::wave_size; ++k) {
+      tv += s_v[k];
+      te += s_e[k];
+    }
+    if (tv)
+      atomicAdd(&counters[gunrock::hip::kernels::C_OUT], tv);
+    if (te)
+      atomicAdd(&counters[gunrock::hip::kernels::C_WORK], te);
+    if (blockIdx.x == 0)
+      atomicAdd(&counters[gunrock::hip::kernels::C_SELECT], (unsigned long long)(ap[source + 1] - ap[source]));
+  }
+}
+
+/// vertices_reached / edges_traversed of a finished traversal and the source's degree (returned),
+/// outside the timed region: one kernel + one counters hand-off.
+template <typename label_t>
+long long reach_stats(grx_graph_s* g, const label_t* d_labels, label_t unreached, int32_t source,
+                      gcuda::standard_context_t& ctx, grx_stats* stats) {
   if (!stats)
-    return;
-  const int32_t* ap = g->d_ap;
-  const std::size_t n = (std::size_t)g->n_rows;
-  stats->vertices_reached = (int64_t)hip::transform_reduce(
-      n,
-      [d_labels, unreached] __device__(std::size_t i) -> unsigned long long {
-        return d_labels[i] != unreached ? 1ull : 0ull;
-      },
-      0ull, rocprim::plus<unsigned long long>(), ctx);
-  stats->edges_traversed = (int64_t)hip::transform_reduce(
-      n,
-      [d_labels, unreached, ap] __device__(std::size_t i) -> unsigned long long {
-        return d_labels[i] != unreached ? (unsigned long long)(ap[i + 1] - ap[i]) : 0ull;
-      },
-      0ull, rocprim::plus<unsigned long long>(), ctx);
+    return 0;
+  const int64_t n = g->n_rows;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx.compute_units() * 8);
+  reach_stats_kernel<label_t><<<grid ? grid : 1, 256, 0, ctx.stream()>>>(d_labels, unreached, g->d_ap, n, source,
+                                                                 ctx.workspace().counters());
+  GRX_HIP_CHECK(hipGetLastError());
+  unsigned long long* m = operators::advance::detail::fetch_counters(ctx);
+  stats->vertices_reached = (int64_t)m[hip::kernels::C_OUT];
+  stats->edges_traversed = (int64_t)m[hip::kernels::C_WORK];
+  return (long long)m[hip::kernels::C_SELECT];
 }
 
 }  // namespace essentials_amd

@@ -64,9 +64,14 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
   void reset() override {
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
-    hip::fill(depth, n, std::numeric_limits<vertex_t>::max(), ctx->stream());
-    hip::fill(depth + source, 1, vertex_t(0), ctx->stream());
-    ctx->synchronize();
+    // one pass, enqueued on the context's stream ahead of the traversal: nothing to wait for
+    vertex_t* d = depth;
+    const vertex_t s = source;
+    hip::for_each_index(
+        n, [d, s] __device__(std::size_t i) {
+          d[i] = (vertex_t)i == s ? vertex_t(0) : std::numeric_limits<vertex_t>::max();
+        },
+        ctx->stream());
     log = level_log_t();
   }
 };
@@ -84,8 +89,8 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
                 enactor_properties_t props = enactor_properties_t())
       : base_t(p, ctx, props) {}
 
-  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
-    f->push_back(this->get_problem()->source);
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t& context) override {
+    f->push_back(this->get_problem()->source, context.get_context(0)->stream());
   }
 
   bool is_converged(gcuda::multi_context_t& context) override {
@@ -151,8 +156,8 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
     unexplored = (unsigned long long)g.get_number_of_edges();
   }
 
-  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
-    f->push_back(this->get_problem()->source);
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t& context) override {
+    f->push_back(this->get_problem()->source, context.get_context(0)->stream());
   }
 
   bool is_converged(gcuda::multi_context_t& context) override {
@@ -262,10 +267,15 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   void reset() override {
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
-    hip::fill(distance, n, std::numeric_limits<weight_t>::max(), ctx->stream());
-    hip::fill(distance + source, 1, weight_t(0), ctx->stream());
-    hip::fill(stamp.data(), n, -1, ctx->stream());
-    ctx->synchronize();
+    weight_t* d = distance;
+    int* st = stamp.data();
+    const vertex_t s = source;
+    hip::for_each_index(
+        n, [d, st, s] __device__(std::size_t i) {
+          d[i] = (vertex_t)i == s ? weight_t(0) : std::numeric_limits<weight_t>::max();
+          st[i] = -1;
+        },
+        ctx->stream());
     log = level_log_t();
   }
 };
@@ -278,13 +288,12 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
   using weight_t = typename problem_type::weight_t;
   using frontier_t = typename base_t::frontier_t;
   int max_iterations = 0;
-
   sssp_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                  enactor_properties_t props = enactor_properties_t())
       : base_t(p, ctx, props) {}
 
-  void prepare_frontier(frontier_t* f, gcuda::multi_context_t&) override {
-    f->push_back(this->get_problem()->source);
+  void prepare_frontier(frontier_t* f, gcuda::multi_context_t& context) override {
+    f->push_back(this->get_problem()->source, context.get_context(0)->stream());
   }
 
   bool is_converged(gcuda::multi_context_t& context) override {

@@ -152,6 +152,17 @@ class frontier_t {
     work_hint_ = unknown_work;
   }
 
+  /// Device-side append of one element, ENQUEUED on `stream` (no host copy, nothing awaited):
+  /// for callers whose next operator runs on that stream anyway.
+  void push_back(type_t const& value, hipStream_t stream) {
+    if (num_elements_ + 1 > get_capacity())
+      storage_->reserve(get_capacity() ? 2 * get_capacity() : 64, num_elements_, stream);
+    detail::fill_kernel<<<1, 64, 0, stream>>>(data() + num_elements_, std::size_t(1), value);
+    GRX_HIP_CHECK(hipGetLastError());
+    ++num_elements_;
+    work_hint_ = unknown_work;
+  }
+
   void fill(type_t const value, hipStream_t stream = nullptr) {
     work_hint_ = unknown_work;
     if (!num_elements_)

@@ -325,7 +325,23 @@ void execute(graph_t& G,
   const std::size_t capacity = has_out ? output.get_capacity() : 0;
 
   detail::clocked_t clock(context);
-  if (holes) {
+  // wide frontiers: hub pre-pass + ONE kernel that expands tiles and then claims hub chunks
+  // dynamically (advance_kernels.hxx: classify_hubs_kernel / expand_fused_kernel)
+  const std::size_t fused_from = context.options().fused_min_slots;
+  if (!holes && !dynamic_tiles && fused_from && n_in >= fused_from) {
+    // scratch: [8 claim cursors, one 128-B line each | hub mask, one bit per input slot]
+    auto* cursors = reinterpret_cast<unsigned long long*>(context.workspace().scratch(
+        (8 * k::CLAIM_LINE + (n_in + 63) / 64) * sizeof(unsigned long long)));
+    auto* mask = cursors + 8 * k::CLAIM_LINE;
+    k::classify_hubs_kernel<input_type>
+        <<<detail::grid_for(n_in, k::CLASSIFY_TILE, (unsigned)context.compute_units() * 8u), k::ADV_BLOCK,
+           0, context.stream()>>>(G, input.data(), n_in, nullptr, chunks, chunk_capacity, hub_threshold,
+                                  chunk_edges, mask, cursors, counters);
+    const unsigned fgrid = (unsigned)context.compute_units() * context.options().fused_blocks_per_cu;
+    k::expand_fused_kernel<input_type, output_type><<<fgrid, k::ADV_BLOCK, 0, context.stream()>>>(
+        G, op, input.data(), n_in, nullptr, out_ptr, capacity, counters, chunks, chunk_capacity, mask,
+        cursors);
+  } else if (holes) {
     k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
                                                       counters, chunks, chunk_capacity,

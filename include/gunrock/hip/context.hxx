@@ -109,7 +109,11 @@ class workspace_t {
   unsigned long long next_sequence() { return ++sequence_; }
 
   /// Growable untyped scratch (rocPRIM temp storage, block counts, flag words).
+  /// Never null, also for a request of 0 bytes: rocPRIM reads a null temporary-storage pointer
+  /// as a size query and then does NOTHING.
   void* scratch(std::size_t bytes) {
+    if (bytes < 256)
+      bytes = 256;
     if (bytes > scratch_.capacity())
       scratch_.reserve(bytes + bytes / 4);
     return scratch_.data();
@@ -171,6 +175,11 @@ struct operator_options_t {
   /// Test hook: cap the hub chunk queue (0 = sized per call) to force the overflow path, in
   /// which a tile expands its hubs in place.
   unsigned long long chunk_queue_limit = 0;
+  /// block_mapped: frontiers of at least this many slots take the fused form (hub pre-pass + one
+  /// kernel for tiles and dynamically claimed hub chunks); 0 = never.
+  std::size_t fused_min_slots = 32768;
+  /// Persistent workgroups per CU of the fused kernel (what is resident at its register use).
+  unsigned fused_blocks_per_cu = 6;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -274,6 +283,10 @@ class standard_context_t {
       options_.tile_width = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_WAVE_CHUNKS"))
       options_.wave_chunks = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GRX_FUSED_MIN_SLOTS"))
+      options_.fused_min_slots = (std::size_t)std::atoll(e);
+    if (const char* e = std::getenv("GRX_FUSED_BLOCKS_PER_CU"))
+      options_.fused_blocks_per_cu = (unsigned)std::atoi(e);
     if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))
       options_.chunk_queue_limit = (unsigned long long)std::atoll(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));

@@ -505,6 +505,278 @@ __global__ void __launch_bounds__(ADV_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
+// block_mapped, FUSED form for wide frontiers: classify_hubs_kernel + expand_fused_kernel.
+//
+// Why: the two-kernel form above (tiles, then hub chunks) leaves the machine half idle while the
+// tile kernel's stragglers finish -- rocprofv3 PMC on RMAT-22 BFS level 2: 96 G L2 requests/s in
+// the tile kernel against 144 G/s in the chunk kernel, mean workgroup busy 56 % of the kernel --
+// and the chunk kernel cannot start before the last tile has queued its hubs.  Here a light
+// pre-pass queues every hub list as chunks and marks the slot in a bit mask (one lane per slot,
+// ~20 us for 2 M slots); then ONE persistent kernel expands its share of the tiles (hub slots
+// skipped) and, as soon as a workgroup has no tile left, claims chunks from eight cursors (one per
+// pool of workgroups dealt to an XCD, the claim for the next chunk requested while the current
+// one is expanded) until the queue is empty: early finishers eat the chunk queue while the
+// heaviest tiles are still running.  Exactly-once is kept by construction: a hub list is reached
+// through its chunks only, every other list through its tile only.
+// ---------------------------------------------------------------------------
+constexpr int CLASSIFY_SLOTS = 8;                          // input slots per thread and super-tile
+constexpr int CLASSIFY_TILE = ADV_BLOCK * CLASSIFY_SLOTS;  // 2048 slots per workgroup step
+constexpr int CLAIM_LINE = 16;   // 64-bit words between two claim cursors (one 128-B line each)
+constexpr int CLAIM_BATCH = 4;   // chunks handed out per claim
+
+template <advance_io_type_t IN, typename graph_t, typename vertex_t, typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    classify_hubs_kernel(graph_t G,
+                         const vertex_t* __restrict__ input,
+                         std::size_t n_in,
+                         const unsigned long long* n_in_device,
+                         chunk_t<vertex_t, edge_t>* chunks,
+                         unsigned long long chunk_capacity,
+                         unsigned hub_threshold,
+                         unsigned chunk_edges,
+                         unsigned long long* __restrict__ hub_mask,
+                         unsigned long long* __restrict__ claim_cursors,
+                         unsigned long long* counters) {
+  __shared__ unsigned s_wave_totals[ADV_WAVES + 1];
+  __shared__ unsigned long long s_base;
+  if (n_in_device)
+    n_in = (std::size_t)__hip_atomic_load(n_in_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  if (blockIdx.x == 0 && tid < 8)  // the expansion kernel's claim cursors start from zero
+    claim_cursors[tid * CLAIM_LINE] = 0ull;
+  // a workgroup takes 2048 CONSECUTIVE slots at a time, eight per thread (eight independent row
+  // lookups in flight per lane), and reserves queue space for all their hubs with ONE atomic
+  const std::size_t n_super = (n_in + CLASSIFY_TILE - 1) / CLASSIFY_TILE;
+  for (std::size_t st = blockIdx.x; st < n_super; st += gridDim.x) {
+    vertex_t v[CLASSIFY_SLOTS];
+    edge_t first[CLASSIFY_SLOTS];
+    unsigned deg[CLASSIFY_SLOTS];
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < CLASSIFY_SLOTS; ++k) {
+      const std::size_t idx = st * CLASSIFY_TILE + (std::size_t)k * ADV_BLOCK + tid;
+      v[k] = gunrock::numeric_limits<vertex_t>::invalid();
+      if (idx < n_in)
+        v[k] = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < CLASSIFY_SLOTS; ++k) {
+      first[k] = 0;
+      deg[k] = 0;
+      if (util::limits::is_valid(v[k])) {
+        first[k] = G.get_starting_edge(v[k]);
+        deg[k] = (unsigned)(G.get_starting_edge(v[k] + 1) - first[k]);
+      }
+      if (deg[k] >= hub_threshold)
+        mine += (deg[k] + chunk_edges - 1) / chunk_edges;
+    }
+    unsigned total = 0;
+    const unsigned excl = block_exclusive_sum<ADV_BLOCK>(mine, total, s_wave_totals);
+    if (total) {  // workgroup-uniform
+      if (tid == 0)
+        s_base = atomicAdd(&counters[C_CHUNKS], (unsigned long long)total);
+      __syncthreads();
+    }
+    unsigned long long at = total ? s_base + excl : 0ull;
+#pragma unroll
+    for (int k = 0; k < CLASSIFY_SLOTS; ++k) {
+      const std::size_t idx = st * CLASSIFY_TILE + (std::size_t)k * ADV_BLOCK + tid;
+      const unsigned my_chunks = (deg[k] >= hub_threshold) ? (deg[k] + chunk_edges - 1) / chunk_edges : 0u;
+      // a list is queued only when ALL its chunks fit; one that does not stays in its tile (slow,
+      // correct) and the slots it reserved below the capacity become empty chunks
+      const bool queued = my_chunks && at + my_chunks <= chunk_capacity;
+      for (unsigned c = 0; c < my_chunks && at + c < chunk_capacity; ++c) {
+        const unsigned off = c * chunk_edges;
+        chunk_t<vertex_t, edge_t> d;
+        d.source = v[k];
+        d.first = first[k] + (edge_t)off;
+        d.count = queued ? (int)((deg[k] - off < chunk_edges) ? deg[k] - off : chunk_edges) : 0;
+        chunks[at + c] = d;
+      }
+      at += my_chunks;
+      // 64 consecutive, 64-aligned slots per wavefront and k: one mask word
+      const unsigned long long word = __ballot(queued);
+      if (lane == 0 && idx < (n_in + wave_size - 1) / wave_size * wave_size)
+        hub_mask[idx / wave_size] = word;
+    }
+    if (total)
+      __syncthreads();  // s_base is rewritten by the next super-tile
+  }
+}
+
+template <advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t,
+          typename edge_t>
+__global__ void __launch_bounds__(ADV_BLOCK)
+    expand_fused_kernel(graph_t G,
+                        op_t op,
+                        const vertex_t* __restrict__ input,
+                        std::size_t n_in,
+                        const unsigned long long* n_in_device,
+                        vertex_t* __restrict__ output,
+                        std::size_t capacity,
+                        unsigned long long* counters,
+                        const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
+                        unsigned long long chunk_capacity,
+                        const unsigned long long* __restrict__ hub_mask,
+                        unsigned long long* __restrict__ claim_cursors) {
+  using weight_t = typename graph_t::weight_type;
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  if (n_in_device)
+    n_in = (std::size_t)__hip_atomic_load(n_in_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  __shared__ vertex_t s_vertex[ADV_BLOCK];
+  __shared__ edge_t s_first[ADV_BLOCK];
+  __shared__ unsigned s_scan[ADV_BLOCK];
+  __shared__ unsigned s_wave_totals[ADV_WAVES + 1];
+  __shared__ unsigned s_counts[ADV_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned long long s_claim;
+  __shared__ vertex_t s_queue[HAS_OUT ? ADV_WAVES * ADV_WQCAP : 1];
+
+  const int tid = threadIdx.x;
+  const int wave = tid / wave_size;
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * ADV_WQCAP : 0), 0u, 0ull};
+  auto degree_of = [&G](vertex_t x) -> unsigned { return (unsigned)G.get_number_of_neighbors(x); };
+
+  // ---- phase 1: this workgroup's tiles (static stride), hub slots skipped -------------------------
+  const unsigned long long n_tiles = (n_in + ADV_BLOCK - 1) / ADV_BLOCK;
+  auto fetch_slot = [&](unsigned long long t, vertex_t& v, edge_t& first, edge_t& last) {
+    v = gunrock::numeric_limits<vertex_t>::invalid();
+    first = last = 0;
+    const std::size_t idx = (std::size_t)t * ADV_BLOCK + tid;
+    if (t < n_tiles && idx < n_in) {
+      const vertex_t x = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      const bool hub = (hub_mask[idx / wave_size] >> (idx % wave_size)) & 1ull;
+      if (util::limits::is_valid(x) && !hub) {
+        v = x;
+        first = G.get_starting_edge(x);
+        last = G.get_starting_edge(x + 1);
+      }
+    }
+  };
+  // operands of the next tile are fetched while this one expands (two dependent global accesses
+  // per tile otherwise sit in front of its first edge)
+  unsigned long long tile = blockIdx.x;
+  vertex_t v, v1;
+  edge_t first, last, first1, last1;
+  fetch_slot(tile, v, first, last);
+  while (tile < n_tiles) {
+    fetch_slot(tile + gridDim.x, v1, first1, last1);
+    const unsigned deg = (unsigned)(last - first);
+    unsigned total;
+    const unsigned excl = block_exclusive_sum<ADV_BLOCK>(deg, total, s_wave_totals);
+    s_vertex[tid] = v;
+    s_first[tid] = first;
+    s_scan[tid] = excl;
+    __syncthreads();
+    for (unsigned i0 = 0; i0 < total; i0 += ADV_BLOCK * ADV_UNROLL) {
+      vertex_t src[ADV_UNROLL], nbr[ADV_UNROLL];
+      edge_t eid[ADV_UNROLL];
+      weight_t wgt[ADV_UNROLL];
+      bool live[ADV_UNROLL];
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        const unsigned i = i0 + k * ADV_BLOCK + tid;
+        live[k] = i < total;
+        if (live[k]) {
+          const int slot = rightmost_le(s_scan, i, ADV_BLOCK);
+          src[k] = s_vertex[slot];
+          eid[k] = s_first[slot] + (edge_t)(i - s_scan[slot]);
+          nbr[k] = G.get_destination_vertex(eid[k]);
+          wgt[k] = G.get_edge_weight(eid[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_UNROLL; ++k) {
+        bool keep = false;
+        if (live[k])
+          keep = op(src[k], nbr[k], eid[k], wgt[k]);
+        if constexpr (HAS_OUT)
+          wq.push_deferred(keep, nbr[k], output, capacity, counters, degree_of);
+      }
+    }
+    __syncthreads();  // the LDS tile arrays are rewritten by the next tile
+    tile += gridDim.x;
+    v = v1;
+    first = first1;
+    last = last1;
+  }
+
+  // ---- phase 2: hub chunks, claimed dynamically ---------------------------------------------------
+  unsigned long long n_chunks =
+      __hip_atomic_load(&counters[C_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n_chunks > chunk_capacity)
+    n_chunks = chunk_capacity;
+  if (n_chunks) {  // grid-uniform
+    // Chunks are handed out in batches of CLAIM_BATCH through eight cursors, each on a cache line
+    // of its own (a single line retires ~90 atomics/us, and cursors sharing one line share that
+    // rate): pool p owns batches p, p + P, p + 2P, ...; workgroups of one XCD (blockIdx % 8) start
+    // on one pool and move on to the next when theirs is exhausted.
+    const unsigned long long n_batches = (n_chunks + CLAIM_BATCH - 1) / CLAIM_BATCH;
+    const unsigned pools = gridDim.x < 8u ? gridDim.x : 8u;
+    unsigned pool = blockIdx.x % pools;
+    unsigned tried = 0;              // thread 0: pools found empty so far
+    unsigned long long pending = 0;  // thread 0: cursor value requested, not yet handed out
+    if (tid == 0)
+      pending = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull);
+    for (;;) {
+      if (tid == 0) {
+        unsigned long long b = pending * pools + pool;
+        while (b >= n_batches && ++tried < pools) {  // own pool exhausted: help the next one
+          pool = (pool + 1) % pools;
+          b = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull) * pools + pool;
+        }
+        s_claim = b;
+        if (b < n_batches)  // request the NEXT batch now; its round trip hides behind this one
+          pending = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull);
+      }
+      __syncthreads();
+      const unsigned long long batch = s_claim;
+      __syncthreads();  // s_claim is rewritten by the next claim
+      if (batch >= n_batches)
+        break;
+      const unsigned long long c0 = batch * CLAIM_BATCH;
+      const unsigned long long c1 = c0 + CLAIM_BATCH < n_chunks ? c0 + CLAIM_BATCH : n_chunks;
+      for (unsigned long long c = c0; c < c1; ++c) {
+        const chunk_t<vertex_t, edge_t> d = chunks[c];
+        vertex_t source = d.source;
+        for (int j0 = 0; j0 < d.count; j0 += ADV_BLOCK * ADV_UNROLL) {
+          vertex_t nbr[ADV_UNROLL];
+          edge_t eid[ADV_UNROLL];
+          weight_t wgt[ADV_UNROLL];
+          bool live[ADV_UNROLL];
+#pragma unroll
+          for (int k = 0; k < ADV_UNROLL; ++k) {
+            const int j = j0 + k * ADV_BLOCK + tid;
+            live[k] = j < d.count;
+            if (live[k]) {
+              eid[k] = d.first + (edge_t)j;
+              nbr[k] = G.get_destination_vertex(eid[k]);
+              wgt[k] = G.get_edge_weight(eid[k]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < ADV_UNROLL; ++k) {
+            bool keep = false;
+            if (live[k])
+              keep = op(source, nbr[k], eid[k], wgt[k]);
+            if constexpr (HAS_OUT)
+              wq.push_deferred(keep, nbr[k], output, capacity, counters, degree_of);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (HAS_OUT)
+    drain_block_summing(wq, s_counts, &s_base, output, capacity, counters, degree_of);
+}
+
+// ---------------------------------------------------------------------------
 // Hub chunks: persistent workgroups, one chunk (consecutive edges of one source)
 // at a time, lanes on consecutive edges.
 // ---------------------------------------------------------------------------

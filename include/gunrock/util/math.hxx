@@ -174,6 +174,16 @@ __host__ __device__ __forceinline__ type_t cas(type_t* address, type_t compare, 
 template <typename type_t>
 __host__ __device__ __forceinline__ type_t exch(type_t* address, type_t value) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifndef GRX_ATOMIC_NO_PRETEST
+  // an exchange that would store what the word already holds is a read: linearise it at this
+  // (agent-scope, L2-served) load and skip the memory-side RMW.  "Stamp" idioms -- the first of
+  // many improvers of a vertex in one round wins `exch(&stamp[v], round) != round`, the others
+  // find the stamp set -- issue one RMW per vertex and round instead of one per improvement
+  // (SSSP iteration 1 on RMAT-22: ~4 improvements per vertex, and the kernel runs at the
+  // chip's scattered-atomic rate).
+  if (detail::peek(address) == value)
+    return value;
+#endif
   return ::atomicExch(address, value);
 #else
   type_t old = *address;
