@@ -109,22 +109,88 @@ def cpu_baseline(Ap, Aj, Ax, algo):
 
 def pagerank_leg(ea, ctx, a) -> dict:
     """BASELINE configs[3] stand-in, reported beside the headline (outside the timed region): PageRank
-    on a DIRECTED R-MAT graph, the push scatter pr.hxx performs and the pull form."""
+    on a DIRECTED R-MAT graph, the push scatter pr.hxx performs and the pull form.  Roofline per
+    iteration: 12 B per edge (column, weight, rank word) + 44 B per vertex (offsets,
+    previous rank, scale, and the copy / dangling / fill / error passes) against the time of one
+    iteration of enact()."""
     try:
         g = ea.Graph.rmat(ctx, a.pagerank_scale, a.edge_factor, a.seed, 0, False)
+        nbytes = 12 * g.nnz + 44 * g.n_rows
         out = {"workload": f"PageRank alpha 0.85 tol 1e-6 on directed RMAT scale-{a.pagerank_scale} "
-                           f"edgefactor-{a.edge_factor} ({g.nnz} edges)"}
+                           f"edgefactor-{a.edge_factor} ({g.nnz} edges)",
+               "algorithmic_bytes_per_iteration": nbytes}
+
+        def leg(st):
+            ms = st.elapsed_ms / st.iterations
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            return {"iterations": st.iterations, "ms_per_iteration": ms,
+                    "mteps": g.nnz * st.iterations / st.elapsed_ms / 1e3,
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None}}
         _, st = ea.pagerank(ctx, g, 0.85, 1e-6)
-        out["push"] = {"iterations": st.iterations, "ms_per_iteration": st.elapsed_ms / st.iterations,
-                       "mteps": g.nnz * st.iterations / st.elapsed_ms / 1e3}
+        out["push"] = leg(st)
         g.build_in_edges(ctx)
         _, st = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
-        out["pull"] = {"iterations": st.iterations, "ms_per_iteration": st.elapsed_ms / st.iterations,
-                       "mteps": g.nnz * st.iterations / st.elapsed_ms / 1e3}
+        out["pull"] = leg(st)
         g.close()
         return out
     except Exception as e:   # never lose the headline line to the side leg
         return {"error": str(e)}
+
+
+KERNEL_SOURCES = ("include/gunrock/hip/kernels", "include/gunrock/framework/operators",
+                  "include/gunrock/util/math.hxx", "essentials_amd/csrc/clients.hxx")
+
+
+def kernel_sources_sha() -> str:
+    """Hash of the sources the measured kernels are compiled from: what a committed PMC record
+    (profiles/latest_pmc.json) must have been collected on to describe the kernels this run times."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        path = os.path.join(ROOT, rel)
+        files = [path] if os.path.isfile(path) else sorted(
+            os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs)
+        for f in files:
+            h.update(os.path.relpath(f, ROOT).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def attach_pmc(out: dict, a, world: int) -> None:
+    """HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (the counters
+    cannot be read from inside the bench): profiles/latest_pmc.json, collected by
+    tools/collect_profiles.sh and summarised by tools/summarize_profiles.py, stamped with the git
+    head and the kernel-source hash it was collected on.  `traffic_stale` says whether those
+    sources have changed since."""
+    pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    if not (world == 1 and a.scale == 22 and a.lb == "block_mapped" and os.path.exists(pmc_path)):
+        return
+    pmc = json.load(open(pmc_path))
+    stale = pmc.get("kernel_sources_sha") != kernel_sources_sha()
+    stamp = {"collected_at_git_head": pmc.get("git_head"), "traffic_stale": stale,
+             "source": "profiles/latest_pmc.json"}
+    for key, roof in (("bfs", out.get("roofline")), ("sssp", out.get("roofline_sssp"))):
+        rec = pmc.get("traffic", {}).get(key)
+        if not rec or roof is None:
+            continue
+        roof["traffic"] = rec["bytes_per_traversal"]
+        roof["traffic_detail"] = dict(rec, **stamp)
+        if roof.get("kernel_ms"):
+            roof["measured_frac"] = rec["bytes_per_traversal"] / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    l2 = pmc.get("l2", {})
+    if out.get("roofline") is not None:
+        out["roofline"]["l2_busy_frac"] = l2.get("busy_frac_bfs_advance")
+        out["roofline"]["l2_hit_rate"] = l2.get("hit_rate_bfs_advance")
+    pr = out.get("pagerank")
+    if isinstance(pr, dict):
+        for form in ("push", "pull"):
+            rec = pmc.get("traffic", {}).get("pagerank_" + form)
+            if rec and form in pr and "roofline" in pr[form]:
+                pr[form]["roofline"]["traffic"] = rec["bytes_per_iteration"]
+                pr[form]["roofline"]["traffic_detail"] = dict(rec, **stamp)
+                pr[form]["roofline"]["measured_frac"] = (
+                    rec["bytes_per_iteration"] / (pr[form]["ms_per_iteration"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
 
 
 def free_port() -> int:
@@ -234,6 +300,8 @@ def main():
     for i in range(a.warmup):
         step(sources[i])
     runner.flush_edges()
+    if hasattr(runner, "mark"):
+        runner.mark()
     fence()
     t0 = time.perf_counter()
     edges = 0
@@ -252,19 +320,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    timed_detail = runner.detail()
     # ---- roofline of the dominant kernel (BFS advance), outside the timed region ----
     roof = runner.bfs_roofline(sources[a.warmup], lb)
-    # HBM traffic of the same kernels from the committed PMC passes (rocprofv3 cannot run inside
-    # the bench): profiles/latest_pmc.json, produced by the command recorded in it
-    pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
-    if world == 1 and a.scale == 22 and a.lb == "block_mapped" and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        roof["traffic"] = pmc["traffic_bytes_per_traversal"]
-        roof["l2_busy_frac"] = pmc.get("l2", {}).get("busy_frac_all_bfs_advance_dispatches")
-        roof["l2_hit_rate"] = pmc.get("l2", {}).get("hit_rate_bfs_advance")
-        roof["traffic_note"] = ("bytes per traversal = (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 "
-                                "--pmc passes (profiles/latest_pmc.json); lower bound without the x2: %d"
-                                % pmc["traffic_bytes_per_traversal_lower_bound"])
     out = {
         "metric": "traversed edges/sec (MTEPS) BFS+SSSP on RMAT-%d" % a.scale,
         "value": edges / dt / 1e6,
@@ -285,8 +343,14 @@ def main():
                    "partitioning": "none" if world == 1 else f"1-D vertex ranges x{world}, "
                                    "all-gather of the ranks' output frontiers between supersteps"},
         "roofline": roof,
-        "detail": runner.detail(),
+        "detail": timed_detail,
     }
+    if world == 1 and "sssp" in a.algo:
+        out["roofline_sssp"] = runner.sssp_roofline(sources[a.warmup], lb)
+    if world == 1:
+        bfs_mean = out["detail"].get("bfs", {}).get("enact_ms_mean_over_timed_steps") or 0.0
+        sssp_mean = out["detail"].get("sssp", {}).get("enact_ms_mean_over_timed_steps") or 0.0
+        out["detail"]["outside_enact_ms_per_step"] = out["ms_per_step"] - bfs_mean - sssp_mean
     if world > 1:
         # what ran where: the process group torch sees, the transport the engine's C++ superstep
         # loop used for the data path, one device per rank
@@ -306,6 +370,9 @@ def main():
             sources[a.warmup:a.warmup + min(a.steps, 8)], lb)
     if world == 1 and not a.no_pagerank:
         out["pagerank"] = pagerank_leg(ea, ctx, a)
+    if world == 1:
+        out["runs_in_process"] = dict(runner.runs)   # what a profile of this command contains
+        attach_pmc(out, a, world)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # timed on the host cores at N = 1 only
             Ap, Aj, Ax = runner.host_csr()

@@ -29,6 +29,7 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
         props.frontier_sizing_factor = o.frontier_sizing_factor;
       enactor_type enactor(&problem, ctx->mc, props);
       enactor.max_iterations = o.max_iterations;
+      enactor.two_pass = o.sssp_two_pass != 0;
       const float ms = enactor.enact();
       if (stats) {
         std::memset(stats, 0, sizeof *stats);

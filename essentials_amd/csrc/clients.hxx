@@ -318,6 +318,25 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
     // separate filter pass (sssp.hxx:126-139, a racy stamp test that lets concurrent duplicates
     // through) is not needed.  Later improvements of the same round still lower distance[dst];
     // the next round reads the latest value.
+    if (two_pass) {
+      // the formulation of the reference client (algorithms/sssp.hxx:110-144), for comparison:
+      // every improvement is emitted, then a bypass filter drops what a (racy) stamp test sees
+      // as already in this round's frontier; surviving duplicates are expanded again next round
+      auto relax_all = [distance] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                      edge_t const& edge, weight_t const& w) -> bool {
+        weight_t through = thread::load(&distance[src]) + w;
+        return through < math::atomic::min(&distance[dst], through);
+      };
+      auto once = [stamp, round] __host__ __device__(vertex_t const& v) -> bool {
+        if (stamp[v] == round)
+          return false;
+        stamp[v] = round;
+        return true;
+      };
+      operators::advance::execute<lb>(G, E, relax_all, context);
+      operators::filter::execute<operators::filter_algorithm_t::bypass>(G, E, once, context);
+      return;
+    }
     auto relax = [distance, stamp, round] __host__ __device__(
                      vertex_t const& src, vertex_t const& dst, edge_t const& edge,
                      weight_t const& w) -> bool {

@@ -69,6 +69,8 @@ class SingleRunner:
         self.dist = torch.empty(self.n, dtype=torch.float32, device=dev)
         self._host = None
         self.last = {}
+        self.runs = {"bfs": 0, "sssp": 0, "sssp_two_pass": 0, "bfs_direction_optimized": 0}
+        self.enact_ms = {"bfs": [], "sssp": []}   # per timed call (reset by flush_edges)
 
     def host_csr(self):
         if self._host is None:
@@ -81,15 +83,58 @@ class SingleRunner:
     def bfs(self, source: int, opts: ea.Options) -> int:
         _, st = ea.bfs(self.ctx, self.g, source, self.depth, opts)
         self.last["bfs"] = st
+        self.runs["bfs"] += 1
+        self.enact_ms["bfs"].append(st.elapsed_ms)
         return st.edges_traversed
 
     def sssp(self, source: int, opts: ea.Options) -> int:
         _, st = ea.sssp(self.ctx, self.g, source, self.dist, opts)
         self.last["sssp"] = st
+        self.runs["sssp"] += 1
+        self.enact_ms["sssp"].append(st.elapsed_ms)
         return st.edges_traversed
 
     def flush_edges(self) -> int:
         return 0   # bfs() / sssp() already returned their counts
+
+    def mark(self) -> None:
+        """Start a new window of per-call enact times (bench: the timed steps)."""
+        self.enact_ms = {"bfs": [], "sssp": []}
+
+    def sssp_roofline(self, source: int, lb) -> dict:
+        """SSSP advance = 12 B per relaxation executed (column index, weight, distance
+        gather) + 20 B per valid frontier entry; the reference's two-pass form adds 8 B per entry
+        (bypass filter: read + write).  Kernel time = HIP events around every advance launch."""
+        best = None
+        for _ in range(3):
+            _, st = ea.sssp(self.ctx, self.g, source, self.dist,
+                            ea.Options(load_balance=lb, collect_kernel_time=True))
+            self.runs["sssp"] += 1
+            if best is None or st.advance_kernel_ms < best.advance_kernel_ms:
+                best = st
+        relax, slots = best.edges_expanded, sum(best.frontier_slots)
+        nbytes = 12 * relax + 20 * slots
+        achieved = nbytes / (best.advance_kernel_ms * 1e-3) / 1e9
+        two = None
+        for _ in range(3):
+            _, st = ea.sssp(self.ctx, self.g, source, self.dist,
+                            ea.Options(load_balance=lb, sssp_two_pass=True))
+            self.runs["sssp_two_pass"] += 1
+            if two is None or st.elapsed_ms < two.elapsed_ms:
+                two = st
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "block_mapped advance kernels of one SSSP (relax functor, all iterations)",
+                "algorithmic_bytes": nbytes, "relaxations": relax, "frontier_entries": slots,
+                "kernel_ms": best.advance_kernel_ms, "enact_ms": best.elapsed_ms,
+                "iterations": best.iterations, "source": source,
+                "relaxations_per_second_g": relax / (best.advance_kernel_ms * 1e-3) / 1e9,
+                "two_pass_reference_formulation": {
+                    "enact_ms": two.elapsed_ms, "iterations": two.iterations,
+                    "relaxations": two.edges_expanded, "frontier_entries": sum(two.frontier_slots),
+                    "algorithmic_bytes": 12 * two.edges_expanded + 28 * sum(two.frontier_slots),
+                    "note": "advance + bypass filter with the racy stamp test, as reference "
+                            "algorithms/sssp.hxx:110-144 (grx_options.sssp_two_pass); same distances"}}
 
     def bfs_roofline(self, source: int, lb) -> dict:
         """Kernel-level roofline of one BFS: HIP events around every advance launch."""
@@ -97,6 +142,7 @@ class SingleRunner:
         for _ in range(3):
             _, st = ea.bfs(self.ctx, self.g, source, self.depth,
                            ea.Options(load_balance=lb, collect_kernel_time=True))
+            self.runs["bfs"] += 1
             if best is None or st.advance_kernel_ms < best.advance_kernel_ms:
                 best = st
         nbytes = bfs_algorithmic_bytes(best.edges_traversed, best.vertices_reached)
@@ -128,6 +174,7 @@ class SingleRunner:
             best = None
             for _ in range(2):
                 _, st = ea.bfs(self.ctx, self.g, s, self.depth, opts)
+                self.runs["bfs_direction_optimized"] += 1
                 if best is None or st.elapsed_ms < best.elapsed_ms:
                     best = st
             ms.append(best.elapsed_ms)
@@ -145,6 +192,8 @@ class SingleRunner:
         d = {}
         for k, st in self.last.items():
             d[k] = {"enact_ms": st.elapsed_ms, "iterations": st.iterations,
+                    "enact_ms_mean_over_timed_steps":
+                        (sum(self.enact_ms[k]) / len(self.enact_ms[k])) if self.enact_ms.get(k) else None,
                     "edges_traversed": st.edges_traversed, "vertices_reached": st.vertices_reached,
                     "mteps_enact": st.edges_traversed / max(st.elapsed_ms, 1e-9) / 1e3,
                     "edges_expanded": st.edges_expanded,

@@ -105,7 +105,10 @@ typedef struct grx_options {
   float do_beta;                /* 0: default 24: push again when frontier vertices < |V| / beta     */
   int32_t chunk_queue_limit;    /* test hook, 0: none. Caps the hub chunk queue to force the overflow
                                    path (hubs expanded in place)                                    */
-  int32_t reserved;
+  int32_t sssp_two_pass;        /* grx_sssp: 0 one pass -- the relax functor keeps exactly one copy of an
+                                   improved vertex per round (atomic::exch on a stamp); 1 the reference
+                                   client's formulation, advance + bypass filter with its racy stamp
+                                   test (algorithms/sssp.hxx:110-144).  Same distances either way       */
 } grx_options;
 
 /* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the

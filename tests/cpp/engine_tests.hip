@@ -3,13 +3,18 @@
 // advance (the form reference algorithms/bc.hxx:140-181 uses), batch, multi-context rejection,
 // and (when built with -DGRX_ADVANCE_LB_OVERRIDE=...) the schedule override.
 // Self-checking: expected values are computed by plain host loops below.  Exit code 0 = pass.
+// With `--dump FILE` the inputs and the DEVICE results of the operator sections (parallel_for,
+// explicit-frontier advance per schedule, filters, uniquify) are also written as JSON, and
+// tests/test_gpu_cpp_surface.py compares them with oracle/ -- the binary is not its own only judge.
 #include <gunrock/algorithms/algorithms.hxx>
 #include <gunrock/hip/algorithms.hxx>
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <numeric>
 #include <set>
+#include <string>
 #include <vector>
 
 using namespace gunrock;
@@ -72,7 +77,23 @@ struct toy_enactor_t : gunrock::enactor_t<problem_type> {
   void loop(gcuda::multi_context_t&) override {}
 };
 
-int main() {
+static FILE* dump = nullptr;
+template <typename T>
+static void dump_array(const char* key, const std::vector<T>& v, bool last = false) {
+  if (!dump)
+    return;
+  std::fprintf(dump, "\"%s\": [", key);
+  for (std::size_t i = 0; i < v.size(); ++i)
+    std::fprintf(dump, i ? ",%lld" : "%lld", (long long)v[i]);
+  std::fprintf(dump, last ? "]\n" : "],\n");
+}
+
+int main(int argc, char** argv) {
+  if (argc == 3 && std::strcmp(argv[1], "--dump") == 0) {
+    dump = std::fopen(argv[2], "w");
+    if (dump)
+      std::fprintf(dump, "{\n");
+  }
   auto mc = std::make_shared<gcuda::multi_context_t>(0);
   auto& ctx = *mc->get_context(0);
   using frontier_t = frontier::frontier_t<vertex_t, edge_t>;
@@ -117,6 +138,12 @@ int main() {
       hg.n, hg.n, (int)hg.aj.size(), d_ap.data(), d_aj.data(), d_ax.data());
   using graph_t = decltype(G);
   CHECK(G.get_number_of_vertices() == hg.n && G.get_number_of_edges() == (int)hg.aj.size());
+  dump_array("row_offsets", hg.ap);
+  dump_array("column_indices", hg.aj);
+  {
+    std::vector<int> w(hg.ax.begin(), hg.ax.end());  // small integers
+    dump_array("values", w);
+  }
 
   // ---- parallel_for -----------------------------------------------------------------------
   {
@@ -125,6 +152,7 @@ int main() {
     auto per_vertex = [G, pdeg] __device__(vertex_t const& v) { pdeg[v] = G.get_number_of_neighbors(v); };
     operators::parallel_for::execute<operators::parallel_for_each_t::vertex>(G, per_vertex, *mc);
     auto h = deg.to_host();
+    dump_array("parallel_for_vertex_degrees", h);
     bool ok = true;
     for (int v = 0; v < hg.n; ++v) ok &= h[v] == hg.ap[v + 1] - hg.ap[v];
     CHECK(ok);
@@ -133,6 +161,7 @@ int main() {
     auto per_edge = [G, psrc] __device__(edge_t const& e) { psrc[e] = G.get_source_vertex(e); };
     operators::parallel_for::execute<operators::parallel_for_each_t::edge>(G, per_edge, *mc);
     auto hs = src.to_host();
+    dump_array("parallel_for_edge_sources", hs);
     ok = true;
     for (int v = 0; v < hg.n; ++v)
       for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) ok &= hs[e] == v;
@@ -159,6 +188,7 @@ int main() {
   for (int v = 0; v < hg.n; v += 3) fin_h.push_back(v);
   fin_h.push_back(-1);
   fin_h.push_back(0);  // the hub twice
+  dump_array("advance_frontier", fin_h);
   std::vector<long long> want_hits(hg.n, 0);
   std::multiset<int> want_out;
   for (int v : fin_h) {
@@ -188,6 +218,11 @@ int main() {
     std::multiset<int> got(out.begin(), out.end());
     got.erase(-1);
     auto hh = hits.to_host();
+    {
+      std::vector<int> sorted_out(got.begin(), got.end());
+      dump_array((std::string("advance_output_") + name).c_str(), sorted_out);
+      dump_array((std::string("advance_calls_per_destination_") + name).c_str(), hh);
+    }
     bool ok = true;
     for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
     if (!(ok && got == want_out)) { std::printf("FAIL schedule %s (vertices->vertices)\n", name); ++failures; }
@@ -221,6 +256,8 @@ int main() {
     operators::filter::execute<operators::filter_algorithm_t::predicated>(G, &E, odd_or_8, *mc);
     CHECK(E.get_input_frontier() != in0);                        // swapped
     CHECK((E.get_input_frontier()->to_host() == std::vector<int>{8, 8, 5}));
+    dump_array("filter_predicated_input", std::vector<int>{8, 2, 8, -1, 5, 2, 2});
+    dump_array("filter_predicated_output", E.get_input_frontier()->to_host());
     operators::filter::execute<operators::filter_algorithm_t::bypass>(G, &E, odd_or_8, *mc, false);
     CHECK((E.get_output_frontier()->to_host() == std::vector<int>{8, 8, 5}));  // no swap asked
     auto* active = E.get_input_frontier();
@@ -228,6 +265,8 @@ int main() {
     operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *mc);
     CHECK(E.get_input_frontier() == active);                     // in place: still the active one
     CHECK((active->to_host() == std::vector<int>{1, 5, 8}));
+    dump_array("uniquify_input", std::vector<int>{8, 8, 5, 1, 5, 1});
+    dump_array("uniquify_output", active->to_host());
     for (int x : {8, 8, 9}) active->push_back(x);                // 1 5 8 8 8 9
     operators::uniquify::execute<operators::uniquify_algorithm_t::unique_copy>(&E, *mc, true);
     CHECK(E.get_input_frontier() != active);                     // copy variant swaps
@@ -344,6 +383,11 @@ int main() {
     for (std::size_t j = 0; j < degsum.size(); ++j) CHECK(degsum[j] == hg.ap[j + 1] - hg.ap[j]);
   }
 
+  if (dump) {
+    dump_array("failures", std::vector<int>{failures}, true);
+    std::fprintf(dump, "}\n");
+    std::fclose(dump);
+  }
   std::printf(failures ? "engine_tests: %d FAILURES\n" : "engine_tests: all passed\n", failures);
   return failures ? 1 : 0;
 }

@@ -21,3 +21,53 @@ def test_cpp_engine_tests(binary):
     r = subprocess.run([path], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "all passed" in r.stdout
+
+
+def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
+    """The device results of engine_tests' operator sections, dumped by the binary, checked HERE
+    against oracle/ (the C restatement of the reference's operator semantics): parallel_for per
+    vertex / per edge, explicit-frontier advance for every schedule (calls per destination and the
+    emitted multiset), predicated filter, uniquify."""
+    import json
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "cpp", "engine_tests")
+    if not os.path.exists(path):
+        from essentials_amd.build import build_cpp_tests
+        build_cpp_tests()
+    out = tmp_path / "dump.json"
+    r = subprocess.run([path, "--dump", str(out)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = json.load(open(out))
+    Ap = np.array(d["row_offsets"], np.int32)
+    Aj = np.array(d["column_indices"], np.int32)
+    Ax = np.array(d["values"], np.float32)
+    n = len(Ap) - 1
+    # parallel_for: vertex -> degree, edge -> its source (orc_advance over the whole graph visits
+    # every edge once and hands (src, dst, edge) to the callback)
+    assert d["parallel_for_vertex_degrees"] == np.diff(Ap).tolist()
+    src_of = np.full(len(Aj), -1, np.int64)
+
+    def note(s, dst, e, w):
+        src_of[e] = s
+        return False
+    oracle.advance(Ap, Aj, Ax, None, note, want_output=False)
+    assert d["parallel_for_edge_sources"] == src_of.tolist()
+    # explicit-frontier advance: op = count the call, keep (s + d) even
+    frontier = np.array(d["advance_frontier"], np.int32)
+    calls = np.zeros(n, np.int64)
+
+    def op(s, dst, e, w):
+        calls[dst] += 1
+        return (s + dst) % 2 == 0
+    want = oracle.advance(Ap, Aj, Ax, frontier, op)
+    want = np.sort(want[want != -1]).tolist()
+    schedules = [k[len("advance_output_"):] for k in d if k.startswith("advance_output_")]
+    assert set(schedules) >= {"block_mapped", "merge_path", "bucketing", "thread_mapped", "warp_mapped",
+                              "work_stealing"}
+    for name in schedules:
+        assert d["advance_output_" + name] == want, name
+        assert d["advance_calls_per_destination_" + name] == calls.tolist(), name
+    keep = oracle.filter_keep(d["filter_predicated_input"], lambda v: v == 8 or (v & 1))
+    assert d["filter_predicated_output"] == keep.tolist()
+    assert d["uniquify_output"] == oracle.uniquify(d["uniquify_input"]).tolist()
+    assert d["failures"] == [0]

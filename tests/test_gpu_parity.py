@@ -359,6 +359,48 @@ def test_bfs_rmat22_properties(ea, ctx, torch):
     assert st0.edges_traversed == int(deg[reached].sum())
 
 
+def test_sssp_rmat22_properties(ea, ctx, torch):
+    """BASELINE configs[2] stand-in at full size (SSSP, bucketing, RMAT-22 with integer-valued
+    weights in [1, 64]: every partial sum is exact, so the fix point is bit-exact and unique).
+    (1) block_mapped, merge_path, bucketing and the reference's two-pass formulation give
+    bit-identical distances; (2) the certificate of shortest-path distances, on the device:
+    dist[src] = 0; dist[v] <= dist[u] + w along every edge of a reached u; every reached
+    non-source vertex has a TIGHT in-edge (the graph is symmetric: in-edges = out-edges)."""
+    g = ea.Graph.rmat(ctx, 22, 16, seed=1, weight_seed=7)
+    src_vertex = 0
+    w0, st0 = ea.sssp(ctx, g, src_vertex)
+    for lb in ("merge_path", "bucketing"):
+        w, st = ea.sssp(ctx, g, src_vertex, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+        assert torch.equal(w.view(torch.int32), w0.view(torch.int32)), lb
+        assert st.edges_traversed == st0.edges_traversed
+    w2, st2 = ea.sssp(ctx, g, src_vertex, options=ea.Options(sssp_two_pass=True))
+    assert torch.equal(w2.view(torch.int32), w0.view(torch.int32))
+    h_ap, h_aj, h_ax = g.to_host()
+    ap = torch.from_numpy(h_ap).cuda()
+    aj = torch.from_numpy(np.ascontiguousarray(h_aj)).cuda().long()
+    ax = torch.from_numpy(np.ascontiguousarray(h_ax)).cuda()
+    deg = (ap[1:] - ap[:-1]).long()
+    u = torch.repeat_interleave(torch.arange(g.n_rows, device="cuda"), deg)
+    INF = float(INF_F)
+    du = w0[u]
+    dv = w0[aj]
+    reached_u = du < INF
+    assert float(w0[src_vertex]) == 0.0
+    assert bool((dv[reached_u] < INF).all())                            # closed under edges
+    through = du[reached_u] + ax[reached_u]
+    assert bool((dv[reached_u] <= through).all())                       # no edge can still relax
+    best = torch.full((g.n_rows,), INF, dtype=torch.float32, device="cuda")
+    cand = torch.where(reached_u, du + ax, torch.full_like(du, INF))
+    best.scatter_reduce_(0, aj, cand, reduce="amin")                    # best candidate over in-edges
+    reached = w0 < INF
+    nonsrc = reached.clone()
+    nonsrc[src_vertex] = False
+    assert bool((best[nonsrc] == w0[nonsrc]).all())                     # tight: a parent exists
+    assert st0.vertices_reached == int(reached.sum())
+    assert st0.edges_traversed == int(deg[reached].sum())
+    assert st0.edges_expanded >= st0.edges_traversed
+
+
 # ---------------------------------------------------------------------------
 # edge cases the reference's harness would hit (empty / degenerate inputs, bad arguments)
 # ---------------------------------------------------------------------------

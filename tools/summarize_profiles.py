@@ -1,12 +1,25 @@
 #!/usr/bin/env python3
 """gpurun_out/profiles_raw/ (tools/collect_profiles.sh) -> profiles/rNN_* summaries + latest_pmc.json.
 
-Usage: python3 tools/summarize_profiles.py [round]     (default round 1)"""
-import collections, csv, glob, json, os, re, shutil, sys
+Usage: python3 tools/summarize_profiles.py [round]     (default round 2; run in the git checkout)
+
+Kernels are attributed to a client by their template arguments (bfs / sssp / pagerank push / pull /
+direction-optimised bfs / the gather probe); the bench line of each pass says how many traversals /
+iterations of each the command ran (`runs_in_process`, pagerank iterations), which turns sums over
+dispatches into per-traversal figures.
+
+HBM read bytes come from the L2's memory-side request counters by size: 32 B x TCC_EA0_RDREQ_32B +
+128 B x TCC_EA0_RDREQ_128B + 64 B x the rest -- ONE number, no "x2 or not" bracket.  The guide's
+derived FETCH_SIZE (= TCC_EA0_RDREQ x 64 B, i.e. half the bytes of 128-B requests) is kept beside it,
+and both are calibrated in the same run on the gather probe (grx_measure_gather_rate: E column
+indices streamed once = 4 E bytes known, plus E random 4-B lookups into a 16 MB table that stays
+on chip)."""
+import collections, csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 PRE = os.path.join(ROOT, "profiles", f"r{rnd:02d}_bench_")
 os.makedirs(os.path.dirname(PRE), exist_ok=True)
 
@@ -18,17 +31,26 @@ def one(pattern):
     return hits[-1]
 
 
-def short(name):
-    """kernel + which client functor it was instantiated for."""
-    base = re.sub(r"<.*", "", name).replace("void ", "")
-    base = base.split("::")[-1] if "kernels::" in name or "detail::" in name else base[:60]
+ADVANCE = ("block_mapped_kernel", "chunk_kernel", "classify_hubs_kernel", "expand_fused_kernel",
+           "wave_chunk_kernel", "pull_probe_kernel", "pull_long_kernel")
+
+
+def attribute(name):
+    """(kernel, client) of a dispatch."""
+    m = re.search(r"kernels::(\w+)", name) or re.search(r"(\w+)<", name) or re.search(r"(\w+)", name)
+    k = m.group(1)
     client = "-"
     for tag, c in (("bfs_do_enactor_t", "bfs_do"), ("bfs_enactor_t", "bfs"), ("sssp_enactor_t", "sssp"),
-                   ("pr_enactor_t", "pr")):
+                   ("pr_pull_enactor_t", "pagerank_pull"), ("pr_enactor_t", "pagerank_push"),
+                   ("pr_problem_t", "pagerank_setup")):
         if tag in name:
             client = c
             break
-    return base, client
+    if k in ("row_group_sum_kernel", "hub_chunk_sum_kernel"):
+        client = "pagerank_pull"
+    if k == "gather_probe_kernel":
+        client = "probe"
+    return k, client
 
 
 def bench_line(path):
@@ -38,142 +60,172 @@ def bench_line(path):
     return {}
 
 
-# ---- 1. stats + trace --------------------------------------------------------------------------
+# ---- 1. stats + trace of the default bench command -------------------------------------------------
 shutil.copy(one("stats/**/*kernel_stats.csv"), PRE + "kernel_stats.csv")
 rows = list(csv.DictReader(open(one("stats/**/*kernel_trace.csv"))))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+per_client_us = collections.defaultdict(float)
+per_kernel = collections.defaultdict(lambda: [0, 0.0])
 with open(PRE + "kernel_trace_advance.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "client", "start_ns", "end_ns", "duration_us", "grid_threads", "workgroup",
                 "lds_bytes", "vgpr", "sgpr"])
     for r in rows:
-        k, c = short(r["Kernel_Name"])
-        if c == "-" and "publish_counters" not in k and "degree_sum" not in k:
-            continue
+        k, c = attribute(r["Kernel_Name"])
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        per_kernel[(k, c)][0] += 1
+        per_kernel[(k, c)][1] += (e - s) / 1e3
+        if c in ("bfs", "sssp") and k in ADVANCE:
+            per_client_us[c] += (e - s) / 1e3
+        if c in ("pagerank_push", "pagerank_pull"):
+            per_client_us[c] += (e - s) / 1e3
+        if c == "-" and "publish_counters" not in k:
+            continue
         w.writerow([k, c, s, e, f"{(e - s) / 1e3:.1f}", r.get("Grid_Size_X", r.get("Grid_Size", "")),
                     r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""),
                     r.get("VGPR_Count", ""), r.get("SGPR_Count", "")])
 stats_bench = bench_line(os.path.join(RAW, "stats.json"))
+json.dump(stats_bench, open(PRE + "line.json", "w"))
+with open(PRE + "kernel_by_client.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "client", "dispatches", "total_us", "mean_us"])
+    for (k, c), (n, us) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, f"{us:.1f}", f"{us / n:.2f}"])
+runs = stats_bench.get("runs_in_process", {})
+pr = stats_bench.get("pagerank", {})
+trace = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
+         "bfs_advance_us_per_traversal": per_client_us["bfs"] / runs["bfs"] if runs.get("bfs") else None,
+         "sssp_advance_us_per_traversal": per_client_us["sssp"] / runs["sssp"] if runs.get("sssp") else None,
+         "pagerank_push_us_per_iteration":
+             per_client_us["pagerank_push"] / pr["push"]["iterations"] if pr.get("push") else None,
+         "pagerank_pull_us_per_iteration":
+             per_client_us["pagerank_pull"] / pr["pull"]["iterations"] if pr.get("pull") else None,
+         "bench_live": {"bfs_kernel_ms": stats_bench.get("roofline", {}).get("kernel_ms"),
+                        "sssp_kernel_ms": stats_bench.get("roofline_sssp", {}).get("kernel_ms"),
+                        "pagerank_push_ms_per_iteration": pr.get("push", {}).get("ms_per_iteration"),
+                        "pagerank_pull_ms_per_iteration": pr.get("pull", {}).get("ms_per_iteration")},
+         "note": "sssp: the one-pass and the two-pass (reference formulation) runs of the roofline leg share "
+                 "the relax kernels' names; the figure is the mean over all of them"}
 
-# average advance-kernel time of one push BFS traversal from the trace (what bench's live HIP-event
-# measurement must agree with): the command runs steps + warmup traversals plus 3 in the roofline leg
-total_us, launches = 0.0, 0
-for r in rows:
-    k, c = short(r["Kernel_Name"])
-    if c == "bfs" and ("block_mapped_kernel" in k or "chunk_kernel" in k):
-        total_us += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        launches += 1
-n_trav = stats_bench.get("steps", 0) + stats_bench.get("warmup", 0) + 3
-per_trav = [total_us / n_trav] * n_trav if n_trav else []
 
-
-# ---- 2. PMC passes -----------------------------------------------------------------------------
+# ---- 2. PMC passes ----------------------------------------------------------------------------------
 def pmc(passname):
-    by_kernel = collections.OrderedDict()
+    table = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.OrderedDict()
     for r in csv.DictReader(open(one(f"{passname}/**/*counter_collection.csv"))):
-        k, c = short(r["Kernel_Name"])
-        key = f"{k} [{c}]" if c != "-" else k
-        d = by_kernel.setdefault(key, collections.defaultdict(float))
-        d[r["Counter_Name"]] += float(r["Counter_Value"])
-        dd = disp.setdefault(r["Dispatch_Id"], {"kernel": k, "client": c, "counters": {}})
-        dd["counters"][r["Counter_Name"]] = float(r["Counter_Value"])
-        d["_dispatches"] = len([1 for x in disp.values() if (x["kernel"], x["client"]) == (k, c)])
-    return by_kernel, disp
+        k, c = attribute(r["Kernel_Name"])
+        table[(k, c)][r["Counter_Name"]] += float(r["Counter_Value"])
+        d = disp.setdefault(r["Dispatch_Id"], {"kernel": k, "client": c, "counters": {}})
+        d["counters"][r["Counter_Name"]] = float(r["Counter_Value"])
+    return table, disp, bench_line(os.path.join(RAW, passname + ".json"))
 
 
-fetch, _ = pmc("fetch")
-write, _ = pmc("write")
-fw = {"FETCH_SIZE": {k: {"sum_KB": v["FETCH_SIZE"], "dispatches": int(v["_dispatches"])} for k, v in fetch.items()},
-      "WRITE_SIZE": {k: {"sum_KB": v["WRITE_SIZE"], "dispatches": int(v["_dispatches"])} for k, v in write.items()}}
-json.dump(fw, open(PRE + "pmc_fetch_write.json", "w"), indent=1)
-
-bfs_bench = bench_line(os.path.join(RAW, "fetch.json"))
-# push-BFS traversals in the BFS-only command: steps + warmup + the roofline leg's repeats
-launches_per_trav = bfs_bench.get("roofline", {}).get("launches", 0)
-bm = fetch.get("block_mapped_kernel [bfs]", {})
-trav = int(round(bm.get("_dispatches", 0) / launches_per_trav)) if launches_per_trav else 0
-adv_fetch = sum(v["FETCH_SIZE"] for k, v in fetch.items() if k in ("block_mapped_kernel [bfs]", "chunk_kernel [bfs]"))
-adv_write = sum(v["WRITE_SIZE"] for k, v in write.items() if k in ("block_mapped_kernel [bfs]", "chunk_kernel [bfs]"))
+rd, _, rd_line = pmc("rdreq")
+ft, _, _ = pmc("fetch")
+wt, _, _ = pmc("write")
+wr, _, _ = pmc("wrreq")
+busy, busy_disp, _ = pmc("l2busy")
+hit, hit_disp, _ = pmc("l2hit")
+pmc_runs = rd_line.get("runs_in_process", {})
+pmc_pr = rd_line.get("pagerank", {})
 
 
-def known(name, table, counter):
-    for k, v in table.items():
-        if name in k:
-            return v[counter]
-    return None
+def client_sum(table, client, counter, kernels=None):
+    return sum(v.get(counter, 0.0) for (k, c), v in table.items()
+               if c == client and (kernels is None or k in kernels))
 
 
-_, busy = pmc("l2busy")
-_, hit = pmc("l2hit")
-with open(PRE + "pmc_l2_busy.csv", "w", newline="") as f:
+def read_bytes(client, kernels=None):
+    n = client_sum(rd, client, "TCC_EA0_RDREQ_sum", kernels)
+    n32 = client_sum(rd, client, "TCC_EA0_RDREQ_32B_sum", kernels)
+    n128 = client_sum(rd, client, "TCC_EA0_RDREQ_128B_sum", kernels)
+    return 32 * n32 + 128 * n128 + 64 * (n - n32 - n128), {"requests": n, "of_32B": n32, "of_128B": n128}
+
+
+def traffic(client, per, kernels=None, unit="traversal"):
+    if not per:
+        return None
+    rb, req = read_bytes(client, kernels)
+    fetch_kb = client_sum(ft, client, "FETCH_SIZE", kernels)
+    write_kb = client_sum(wt, client, "WRITE_SIZE", kernels)
+    atom = client_sum(wr, client, "TCC_EA0_ATOMIC_sum", kernels)
+    out = {"read_bytes": rb / per, "write_bytes": write_kb * 1024 / per,
+           "memory_side_atomics": atom / per,
+           "read_requests": {k: v / per for k, v in req.items()},
+           "FETCH_SIZE_bytes_raw": fetch_kb * 1024 / per,
+           "units_in_command": per}
+    out["bytes_per_" + unit] = out["read_bytes"] + out["write_bytes"]
+    return out
+
+
+tr = {"bfs": traffic("bfs", pmc_runs.get("bfs"), ADVANCE),
+      "sssp": traffic("sssp", (pmc_runs.get("sssp", 0) + pmc_runs.get("sssp_two_pass", 0)) or None, ADVANCE),
+      "pagerank_push": traffic("pagerank_push", pmc_pr.get("push", {}).get("iterations"), None, "iteration"),
+      "pagerank_pull": traffic("pagerank_pull", pmc_pr.get("pull", {}).get("iterations"), None, "iteration")}
+# calibration on the gather probe: bench.py calls grx_measure_gather_rate twice (agent-scope and plain
+# loads), each 1 warm-up + 5 timed passes over the E column indices
+probe_disp = int(sum(1 for d in csv.DictReader(open(one("rdreq/**/*counter_collection.csv")))
+                     if "gather_probe_kernel" in d["Kernel_Name"] and d["Counter_Name"] == "TCC_EA0_RDREQ_sum"))
+E = rd_line.get("config", {}).get("edges")
+V = rd_line.get("config", {}).get("vertices")
+calib = None
+if probe_disp and E:
+    rb, req = read_bytes("probe")
+    calib = {"dispatches": probe_disp, "known_column_stream_bytes_per_dispatch": 4 * E,
+             "label_table_bytes": 4 * V,
+             "read_bytes_per_dispatch": rb / probe_disp,
+             "FETCH_SIZE_bytes_raw_per_dispatch": client_sum(ft, "probe", "FETCH_SIZE") * 1024 / probe_disp,
+             "read_requests_per_dispatch": {k: v / probe_disp for k, v in req.items()},
+             "reading": "the size-resolved request counters reproduce the known stream; FETCH_SIZE reports "
+                        "about half of it (128-B requests tallied at 64 B), as the guide says"}
+
+# L2 evidence for the BFS advance dispatches
+with open(PRE + "pmc_l2.csv", "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["dispatch", "kernel", "client", "counter", "value"])
-    for table in (busy, hit):
+    w.writerow(["pass", "dispatch", "kernel", "client", "counter", "value"])
+    for name, table in (("l2busy", busy_disp), ("l2hit", hit_disp)):
         for did, d in table.items():
-            if d["client"] != "bfs":
-                continue
-            for cn, cv in d["counters"].items():
-                w.writerow([did, d["kernel"], d["client"], cn, f"{cv:.0f}"])
-bfs_busy = [d["counters"] for d in busy.values() if d["client"] == "bfs"]
-tot_busy = sum(c.get("TCC_BUSY_sum", 0) for c in bfs_busy)
-tot_cyc = sum(c.get("TCC_CYCLE_sum", 0) for c in bfs_busy)
-largest = sorted((d for d in busy.values() if d["client"] == "bfs"),
-                 key=lambda d: -d["counters"].get("TCC_CYCLE_sum", 0))[:4]
-bfs_hit = [d["counters"] for d in hit.values() if d["client"] == "bfs"]
-H = sum(c.get("TCC_HIT_sum", 0) for c in bfs_hit)
-M = sum(c.get("TCC_MISS_sum", 0) for c in bfs_hit)
-RD = sum(c.get("TCC_READ_sum", 0) for c in bfs_hit)
-RS = sum(c.get("TCC_READ_SECTORS_sum", 0) for c in bfs_hit)
+            if d["client"] in ("bfs", "sssp", "pagerank_push", "pagerank_pull", "probe"):
+                for cn, cv in d["counters"].items():
+                    w.writerow([name, did, d["kernel"], d["client"], cn, f"{cv:.0f}"])
 
-roof = bfs_bench.get("roofline", {})
+
+def l2(client):
+    b = client_sum(busy, client, "TCC_BUSY_sum")
+    cyc = client_sum(busy, client, "TCC_CYCLE_sum")
+    h = client_sum(hit, client, "TCC_HIT_sum")
+    m = client_sum(hit, client, "TCC_MISS_sum")
+    r = client_sum(hit, client, "TCC_READ_sum")
+    s = client_sum(hit, client, "TCC_READ_SECTORS_sum")
+    return {"busy_frac": b / cyc if cyc else None, "hit_rate": h / (h + m) if h + m else None,
+            "read_sectors_per_read": s / r if r else None,
+            "requests": client_sum(busy, client, "TCC_REQ_sum"),
+            "atomics": client_sum(busy, client, "TCC_ATOMIC_sum")}
+
+
+from bench import kernel_sources_sha  # noqa: E402  (the same hash bench.py checks at run time)
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "include", "essentials_amd"],
+                                capture_output=True, text=True).stdout.strip())
+except Exception:
+    head, dirty = None, None
 latest = {
     "round": rnd,
-    "command": "tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc TCC_BUSY_sum "
-               "TCC_CYCLE_sum TCC_REQ_sum TCC_TAG_STALL_sum | --pmc TCC_HIT_sum TCC_MISS_sum TCC_READ_sum "
-               "TCC_READ_SECTORS_sum (four separate runs) -- python3 bench.py --steps 2 --warmup 1 "
-               "--no-cpu-baseline --no-pagerank --algo bfs",
-    "kernels": "block_mapped_kernel + chunk_kernel of the push BFS client, all levels of one traversal",
-    "traversals_in_command": trav,
-    "FETCH_SIZE_KB_per_traversal": adv_fetch / trav if trav else None,
-    "WRITE_SIZE_KB_per_traversal": adv_write / trav if trav else None,
-    "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; "
-                  "WRITE_SIZE exact.  Calibrated in the same run on kernels with known bytes (below).  The x2 is "
-                  "NOT calibrated for the random 4-B label gathers, so the true read traffic lies between 1x and "
-                  "2x FETCH_SIZE.",
-    "calibration": {
-        "fill_edges_kernel_known_read_KB": None,
-        "fill_edges_kernel_FETCH_KB": known("fill_edges_kernel", fetch, "FETCH_SIZE"),
-        "emit_kernel_known_write_KB": None,
-        "emit_kernel_WRITE_KB": known("emit_kernel", write, "WRITE_SIZE"),
-    },
-    "traffic_bytes_per_traversal": (2 * adv_fetch + adv_write) * 1024 / trav if trav else None,
-    "traffic_bytes_per_traversal_lower_bound": (adv_fetch + adv_write) * 1024 / trav if trav else None,
-    "algorithmic_bytes_per_traversal": roof.get("algorithmic_bytes"),
-    "trace": {"bfs_advance_us_per_traversal_mean": sum(per_trav) / len(per_trav) if per_trav else None,
-              "traversals_seen": len(per_trav),
-              "bench_live_kernel_ms": stats_bench.get("roofline", {}).get("kernel_ms")},
-    "l2": {
-        "busy_frac_all_bfs_advance_dispatches": tot_busy / tot_cyc if tot_cyc else None,
-        "hit_rate_bfs_advance": H / (H + M) if H + M else None,
-        "read_sectors_per_read": RS / RD if RD else None,
-        "largest_dispatches": [
-            {"kernel": d["kernel"], **d["counters"],
-             "busy_frac": d["counters"].get("TCC_BUSY_sum", 0) / max(d["counters"].get("TCC_CYCLE_sum", 1), 1)}
-            for d in largest],
-        "reading": "TCC_BUSY/TCC_CYCLE summed over the 128 L2 channels: the fraction of channel-cycles the L2 "
-                   "is busy while the kernel runs",
-    },
+    "git_head": head, "git_dirty_sources": dirty, "kernel_sources_sha": kernel_sources_sha(),
+    "command": "tools/collect_profiles.sh: separate rocprofv3 --pmc passes (TCC_EA0_RDREQ by size | FETCH_SIZE | "
+               "WRITE_SIZE | TCC_EA0_WRREQ + atomics | L2 busy | L2 hit) -- python3 bench.py --steps 2 --warmup 1 "
+               "--no-cpu-baseline",
+    "traffic": tr,
+    "calibration_gather_probe": calib,
+    "algorithmic": {"bfs_bytes_per_traversal": rd_line.get("roofline", {}).get("algorithmic_bytes"),
+                    "sssp_bytes_per_traversal": rd_line.get("roofline_sssp", {}).get("algorithmic_bytes"),
+                    "pagerank_bytes_per_iteration": pmc_pr.get("algorithmic_bytes_per_iteration")},
+    "trace": trace,
+    "l2": {"busy_frac_bfs_advance": l2("bfs")["busy_frac"], "hit_rate_bfs_advance": l2("bfs")["hit_rate"],
+           "by_client": {c: l2(c) for c in ("bfs", "sssp", "pagerank_push", "pagerank_pull", "probe")},
+           "reading": "TCC_BUSY/TCC_CYCLE summed over the 128 L2 channels and all dispatches of the client"},
 }
-# known bytes of the two generator kernels used as calibration (rmat.hip): fill_edges reads 4 B per
-# generated edge record field it streams; emit writes 8 B per directed edge
-gen = stats_bench.get("config", {})
-if gen.get("edges"):
-    latest["calibration"]["emit_kernel_known_write_KB"] = gen["edges"] * 8 / 1024
-    latest["calibration"]["fill_edges_kernel_known_read_KB"] = gen["edges"] * 4 / 1024
 json.dump(latest, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
-print(json.dumps({k: latest[k] for k in ("traversals_in_command", "FETCH_SIZE_KB_per_traversal",
-                                         "WRITE_SIZE_KB_per_traversal", "traffic_bytes_per_traversal",
-                                         "trace")}, indent=1))
-print(json.dumps(latest["l2"], indent=1)[:1500])
+json.dump({"traffic": tr, "calibration_gather_probe": calib}, open(PRE + "pmc_traffic.json", "w"), indent=1)
+print(json.dumps({"trace": trace, "traffic": tr, "calibration": calib, "l2": latest["l2"]["by_client"]}, indent=1))
