@@ -211,7 +211,9 @@ long long reach_stats(grx_graph_s* g, const label_t* d_labels, label_t unreached
   if (!stats)
     return 0;
   const int64_t n = g->n_rows;
-  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx.compute_units() * 8);
+  // one workgroup per CU: the three result words take one atomic each per workgroup, and a single
+  // device word retires ~90 atomics/us (2048 workgroups made this pass atomic-bound: 57 us)
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx.compute_units());
   reach_stats_kernel<label_t><<<grid ? grid : 1, 256, 0, ctx.stream()>>>(d_labels, unreached, g->d_ap, n, source,
                                                                  ctx.workspace().counters());
   GRX_HIP_CHECK(hipGetLastError());

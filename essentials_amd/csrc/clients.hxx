@@ -288,6 +288,8 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
   using weight_t = typename problem_type::weight_t;
   using frontier_t = typename base_t::frontier_t;
   int max_iterations = 0;
+  bool two_pass = false;  // true: advance + bypass filter, as reference algorithms/sssp.hxx does
+
   sssp_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                  enactor_properties_t props = enactor_properties_t())
       : base_t(p, ctx, props) {}

@@ -25,7 +25,8 @@ os.makedirs(os.path.dirname(PRE), exist_ok=True)
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(RAW, pattern), recursive=True))
+    # gpurun MERGES new files into gpurun_out/: older runs' files may still lie here -- newest wins
+    hits = sorted(glob.glob(os.path.join(RAW, pattern), recursive=True), key=os.path.getmtime)
     if not hits:
         sys.exit(f"missing {pattern} under {RAW}")
     return hits[-1]
