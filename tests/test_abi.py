@@ -38,10 +38,38 @@ def test_python_binding_covers_the_header():
     assert sorted(_SIGNATURES) == declared_functions()
 
 
-def test_struct_layouts_match_header():
-    from essentials_amd.api import _Options, _Stats
+def test_struct_layouts_match_header(tmp_path):
+    """Every struct that crosses the C ABI: size and the offset of every field as a C compiler
+    lays the header out (gcc on include/essentials_amd.h) against the ctypes mirror in api.py."""
+    from essentials_amd.api import _Options, _PartitionedStats, _Stats
     assert C.sizeof(_Options) == 12 * 4         # 12 x int32/float
     assert C.sizeof(_Stats) == 4 * 4 + 2 * 8 + 2 * 4 + 64 * 8 + 8
+    mirrors = {"grx_options": _Options, "grx_stats": _Stats, "grx_partitioned_stats": _PartitionedStats}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, mirror in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe)])
+    seen = set()
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, field, value = line.split()
+        mirror = mirrors[cname]
+        if field == "size":
+            assert C.sizeof(mirror) == int(value), cname
+        else:
+            assert getattr(mirror, field).offset == int(value), (cname, field)
+            seen.add((cname, field))
+    # and no field of the header is missing from the mirror (count the members of each struct)
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, mirror in mirrors.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        members = [m for m in body.split(";") if m.strip()]
+        assert len(members) == len(mirror._fields_), (cname, members)
 
 
 def test_no_gpu_means_loud_failure(lib):
