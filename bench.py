@@ -255,6 +255,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    # stdout carries exactly ONE JSON line: whatever libraries print there meanwhile (gloo's
+    # connection notice, profiler banners) is sent to stderr until the line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     # GRX_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU
     backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
     device = local_rank % max(torch.cuda.device_count(), 1)
@@ -381,6 +386,8 @@ def main():
                 out["cpu_baseline_strong"] = cpu_baseline_strong(Ap, Aj)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
