@@ -42,7 +42,10 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
   # runs: .github/workflows/ubuntu.yml:52-79), compiled in place and unmodified against this
   # repository's include/.  The reference's include/ is searched AFTER ours and only its
   # algorithms/{bfs,sssp,pr}.hxx may come from there: the dependency file is checked.
-  for a in bfs sssp pr; do
+  # bfs / sssp / pr are the hot path's clients; kcore, ppr and bc are the heaviest users of the
+  # operators beside it (predicated filters whose predicates have side effects,
+  # parallel_for, batch, merge_path over explicit frontiers) and run here purely as drop-in evidence
+  for a in bfs sssp pr kcore ppr bc; do
     hipcc -x hip -std=c++17 -O3 --offload-arch=gfx950 \
       -Wno-inconsistent-missing-override -Wno-unused-result \
       -I "$repo/include" -idirafter "$ref/include" -MD -MF "$out/ref_$a.d" \
