@@ -142,6 +142,53 @@ class graph_csr_t {
     return static_cast<edge_t>(-1);
   }
 
+  /**
+   * @brief Common neighbours of two vertices whose rows have ASCENDING column ids:
+   * on_intersection(w) is called for every w in both lists (once per matching pair of entries),
+   * the number of calls is returned (reference graph/csr.hxx:110-167; triangle counting's inner
+   * loop, algorithms/tc.hxx:81-94).  The shorter list is walked; in the longer one the search
+   * resumes where the previous element was found (galloping binary search), so the cost is
+   * O(short * log(long / short)) instead of the two-pointer walk's O(short + long).
+   */
+  template <typename operator_type>
+  __host__ __device__ __forceinline__ vertex_t get_intersection_count(vertex_t const& source,
+                                                                      vertex_t const& destination,
+                                                                      operator_type on_intersection) const {
+    edge_t a = offsets[source], a_end = offsets[source + 1];
+    edge_t b = offsets[destination], b_end = offsets[destination + 1];
+    if (a_end - a > b_end - b) {  // a = the shorter list
+      edge_t t = a; a = b; b = t;
+      t = a_end; a_end = b_end; b_end = t;
+    }
+    vertex_t count = 0;
+    for (; a < a_end && b < b_end; ++a) {
+      const vertex_t x = indices[a];
+      // first position in [b, b_end) whose column is >= x: gallop, then bisect
+      edge_t step = 1, lo = b, hi = b;
+      while (hi < b_end && indices[hi] < x) {
+        lo = hi + 1;
+        hi += step;
+        step *= 2;
+      }
+      if (hi > b_end)
+        hi = b_end;
+      while (lo < hi) {
+        const edge_t mid = lo + (hi - lo) / 2;
+        if (indices[mid] < x)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      b = lo;
+      if (b < b_end && indices[b] == x) {
+        ++count;
+        ++b;
+        on_intersection(x);
+      }
+    }
+    return count;
+  }
+
   __host__ __device__ __forceinline__ edge_t* get_row_offsets() const { return offsets; }
   __host__ __device__ __forceinline__ vertex_t* get_column_indices() const { return indices; }
   __host__ __device__ __forceinline__ weight_t* get_nonzero_values() const { return values; }

@@ -54,7 +54,7 @@ def build(force: bool = False) -> None:
         inputs += [os.path.join(_HERE, f) for f in ("ref_build.sh", "ref_clients_driver.cpp", "ref_driver.cpp")]
         newest = max(os.path.getmtime(f) for f in inputs)
         outputs = [_REF, _REF_CLIENTS, _REF_CLIENTS.replace(".so", "_bucketing.so")]
-        outputs += [os.path.join(_HERE, "_ref", "ref_" + a) for a in ("bfs", "sssp", "pr", "kcore", "ppr", "bc")]
+        outputs += [os.path.join(_HERE, "_ref", "ref_" + a) for a in ("bfs", "sssp", "pr", "kcore", "ppr", "bc", "color")]
         if force or any(not os.path.exists(o) or os.path.getmtime(o) < newest for o in outputs):
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -312,6 +312,16 @@ class RefClients:
             L.refc_bfs_job.argtypes = job
             L.refc_sssp_job.argtypes = job
             L.refc_pr_job_refused.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp]
+
+    def tc(self, ap, aj, ax, counts):
+        """tc::run(G, reduce_all=True, counts, &total) -> total triangles."""
+        ms, total = C.c_float(), C.c_ulonglong()
+        self.L.refc_tc.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(C.c_ulonglong),
+                                                                           C.POINTER(C.c_float)]
+        rc = self.L.refc_tc(ap.numel() - 1, aj.numel(), ap.data_ptr(), aj.data_ptr(), ax.data_ptr(),
+                            counts.data_ptr(), total, ms)
+        assert rc == 0
+        return total.value
 
     def run_job(self, algo, ap, aj, ax, source, out, rank, world, lo, hi, unique_id=None,
                 all_gather=None, all_reduce=None):

@@ -9,6 +9,11 @@
 #include GRX_REF_BFS_HXX
 #include GRX_REF_SSSP_HXX
 #include GRX_REF_PR_HXX
+#ifdef GRX_REF_TC_HXX
+#include GRX_REF_TC_HXX  // triangle counting: block_mapped graph -> none advance + set intersections;
+                         // the only algorithm whose results the reference's unit tests pin
+                         // (unittests/algorithms/tc.cuh:19-93)
+#endif
 
 using namespace gunrock;
 
@@ -131,3 +136,19 @@ extern "C" int refc_pr_job_refused(int n, int nnz, int* d_ap, int* d_aj, float* 
     return std::string(e.what()).find("replica") != std::string::npos ? 1 : -1;
   }
 }
+
+#ifdef GRX_REF_TC_HXX
+extern "C" int refc_tc(int n, int nnz, int* d_ap, int* d_aj, float* d_ax, int* d_vertex_triangles,
+                       unsigned long long* total, float* ms) {
+  try {
+    auto G = make_graph(n, nnz, d_ap, d_aj, d_ax);
+    std::size_t t = 0;
+    *ms = gunrock::tc::run(G, true, d_vertex_triangles, &t);
+    *total = (unsigned long long)t;
+    return 0;
+  } catch (std::exception& e) {
+    std::fprintf(stderr, "refc_tc: %s\n", e.what());
+    return -1;
+  }
+}
+#endif

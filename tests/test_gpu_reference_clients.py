@@ -157,9 +157,9 @@ def test_reference_headers_as_a_partitioned_job_of_one_on_rccl(refc, oracle, gol
     assert refc.pr_job_refused(dev(Ap), dev(Aj), dev(Ax), p, ea.Context.unique_id())
 
 
-@pytest.mark.parametrize("algo", ["kcore", "ppr"])
+@pytest.mark.parametrize("algo", ["kcore", "ppr", "color"])
 def test_reference_neighbour_harnesses(algo):
-    """Beyond the hot path's three clients: the reference's kcore and ppr example harnesses (and
+    """Beyond the hot path's three clients: the reference's kcore, ppr and color example harnesses (and
     their algorithm headers), compiled in place and unmodified against include/gunrock, checked by
     the reference's OWN CPU implementations inside the harness (kcore_cpu.hxx, ppr_cpu.hxx).  They
     lean on the operators next to advance -- predicated filters whose predicates have side effects
@@ -218,3 +218,20 @@ def test_reference_bc_harness_against_brandes(oracle):
     k = len(got)
     scale = 1.0 if np.allclose(got, bc[:k], rtol=1e-3, atol=1e-3) else 0.5
     assert np.allclose(got, bc[:k] * scale, rtol=1e-3, atol=1e-3), (got[:8], bc[:8])
+
+
+def test_reference_tc_known_answers(refc):
+    """The reference's only pinned algorithm results (unittests/algorithms/tc.cuh:19-93): its
+    unchanged tc.hxx -- a block_mapped graph -> none advance whose functor intersects neighbour
+    lists -- on this engine must give the triangle counts the reference's unit tests expect."""
+    import torch
+    if not hasattr(refc.L, "refc_tc"):
+        pytest.skip("libgrx_ref_clients.so predates the tc entry point")
+    for Ap, Aj in (([0, 3, 5, 8, 10], [1, 2, 3, 0, 2, 0, 1, 3, 0, 2]),                 # tc.cuh:22-31
+                   ([0, 4, 7, 10, 12], [0, 1, 2, 3, 0, 1, 2, 0, 1, 3, 0, 2])):        # :59-70 (self loop)
+        ap = dev(np.array(Ap, np.int32))
+        aj = dev(np.array(Aj, np.int32))
+        ax = dev(np.zeros(len(Aj), np.float32))
+        counts = torch.zeros(4, dtype=torch.int32, device="cuda")
+        total = refc.tc(ap, aj, ax, counts)
+        assert counts.cpu().tolist() == [2, 1, 2, 1] and total == 6           # tc.cuh:46-55, :85-93
