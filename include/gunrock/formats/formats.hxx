@@ -25,6 +25,9 @@ using memory::memory_space_t;
 
 template <memory_space_t space, typename index_t, typename offset_t, typename value_t>
 struct coo_t {
+  using index_type = index_t;
+  using offset_type = offset_t;
+  using value_type = value_t;
   index_t number_of_rows{0};
   index_t number_of_columns{0};
   offset_t number_of_nonzeros{0};
@@ -40,6 +43,9 @@ struct coo_t {
 
 template <memory_space_t space, typename index_t, typename offset_t, typename value_t>
 struct csr_t {
+  using index_type = index_t;    // harness checkers name them (examples/algorithms/spmv/spmv_cpu.hxx:28-30)
+  using offset_type = offset_t;
+  using value_type = value_t;
   index_t number_of_rows{0};
   index_t number_of_columns{0};
   offset_t number_of_nonzeros{0};

@@ -4,3 +4,4 @@
 #include <gunrock/framework/operators/advance.hxx>
 #include <gunrock/framework/operators/filter.hxx>
 #include <gunrock/framework/operators/batch.hxx>
+#include <gunrock/framework/operators/neighborreduce.hxx>

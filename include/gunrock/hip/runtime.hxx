@@ -296,9 +296,15 @@ class device_array_t {
       GRX_HIP_CHECK(hipMemcpy(h.data(), buf_.data(), size_ * sizeof(type_t), hipMemcpyDeviceToHost));
     return h;
   }
+  /// With a stream: enqueued there.  Without one: complete when the call returns -- a memset on
+  /// the null stream is NOT ordered before work on the engine's non-blocking streams, and it may
+  /// still be in flight when hipMemsetAsync returns.
   void zero(hipStream_t stream = nullptr) {
-    if (size_)
-      GRX_HIP_CHECK(hipMemsetAsync(buf_.data(), 0, size_ * sizeof(type_t), stream));
+    if (!size_)
+      return;
+    GRX_HIP_CHECK(hipMemsetAsync(buf_.data(), 0, size_ * sizeof(type_t), stream));
+    if (!stream)
+      GRX_HIP_CHECK(hipStreamSynchronize(nullptr));
   }
   void set_parking(bool park) { buf_.set_parking(park); }
 

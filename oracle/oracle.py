@@ -54,7 +54,7 @@ def build(force: bool = False) -> None:
         inputs += [os.path.join(_HERE, f) for f in ("ref_build.sh", "ref_clients_driver.cpp", "ref_driver.cpp")]
         newest = max(os.path.getmtime(f) for f in inputs)
         outputs = [_REF, _REF_CLIENTS, _REF_CLIENTS.replace(".so", "_bucketing.so")]
-        outputs += [os.path.join(_HERE, "_ref", "ref_" + a) for a in ("bfs", "sssp", "pr", "kcore", "ppr", "bc", "color")]
+        outputs += [os.path.join(_HERE, "_ref", "ref_" + a) for a in ("bfs", "sssp", "pr", "kcore", "ppr", "bc", "color", "spmv")]
         if force or any(not os.path.exists(o) or os.path.getmtime(o) < newest for o in outputs):
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 

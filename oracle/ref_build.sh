@@ -47,7 +47,7 @@ if [ "${GRX_SKIP_REF_CLIENTS:-0}" != "1" ]; then
   # bfs / sssp / pr are the hot path's clients; kcore, ppr and bc are the heaviest users of the
   # operators beside it (predicated filters whose predicates have side effects,
   # parallel_for, batch, merge_path over explicit frontiers) and run here purely as drop-in evidence
-  for a in bfs sssp pr kcore ppr bc color; do
+  for a in bfs sssp pr kcore ppr bc color spmv; do
     hipcc -x hip -std=c++17 -O3 --offload-arch=gfx950 \
       -Wno-inconsistent-missing-override -Wno-unused-result \
       -I "$repo/include" -idirafter "$ref/include" -MD -MF "$out/ref_$a.d" \

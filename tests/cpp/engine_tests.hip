@@ -245,6 +245,49 @@ int main(int argc, char** argv) {
   run_schedule(std::integral_constant<lbt, lbt::bucketing>(), "bucketing");
   run_schedule(std::integral_constant<lbt, lbt::work_stealing>(), "work_stealing");
 
+  // ---- neighborreduce: per-vertex reduction over out-edges (reference neighborreduce.hxx:55-101) ---
+  {
+    using problem_type = toy_problem_t<graph_t>;
+    problem_type P(G, mc);
+    toy_enactor_t<problem_type> E(&P, mc);
+    hip::device_array_t<float> y(hg.n);
+    float* py = y.data();
+    std::vector<float> xs(hg.n);
+    for (int v = 0; v < hg.n; ++v) xs[v] = (float)(v % 7);     // small integers: float sums are exact
+    auto d_x = upload(xs);
+    const float* px = d_x.data();
+    auto term = [G, px] __host__ __device__(edge_t e) -> float {
+      return G.get_edge_weight(e) * px[G.get_destination_vertex(e)];
+    };
+    auto plus = [] __host__ __device__(float a, float b) -> float { return a + b; };
+    operators::neighborreduce::execute(G, &E, py, term, plus, 0.0f, *mc);
+    auto hy = y.to_host();
+    bool ok = true;
+    for (int v = 0; v < hg.n; ++v) {
+      float want = 0;
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) want += hg.ax[e] * xs[hg.aj[e]];
+      ok &= hy[v] == want;
+    }
+    CHECK(ok);  // includes the hub row (5000 edges) and the edgeless rows (0)
+    {
+      std::vector<long long> as_int(hy.begin(), hy.end());
+      dump_array("neighborreduce_sum_w_times_x", as_int);
+    }
+    // another monoid: maximum column id per row (-1 for an edgeless row)
+    hip::device_array_t<int> mx(hg.n);
+    auto col = [G] __host__ __device__(edge_t e) -> int { return G.get_destination_vertex(e); };
+    auto maxi = [] __host__ __device__(int a, int b) -> int { return a > b ? a : b; };
+    operators::neighborreduce::execute(G, &E, mx.data(), col, maxi, -1, *mc);
+    auto hm = mx.to_host();
+    ok = true;
+    for (int v = 0; v < hg.n; ++v) {
+      int want = -1;
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) want = std::max(want, hg.aj[e]);
+      ok &= hm[v] == want;
+    }
+    CHECK(ok);
+  }
+
   // ---- enactor overloads: which frontier is active afterwards ------------------------------
   {
     using problem_type = toy_problem_t<graph_t>;

@@ -67,6 +67,11 @@ def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
     for name in schedules:
         assert d["advance_output_" + name] == want, name
         assert d["advance_calls_per_destination_" + name] == calls.tolist(), name
+    # neighborreduce: y[v] = sum over out-edges of w * x[dst], x[v] = v % 7 (exact in float)
+    x = (np.arange(n) % 7).astype(np.float64)
+    want_y = np.add.reduceat(np.concatenate([Ax * x[Aj], [0.0]]), np.minimum(Ap[:-1], len(Aj)))
+    want_y[np.diff(Ap) == 0] = 0.0
+    assert d["neighborreduce_sum_w_times_x"] == want_y.astype(np.int64).tolist()
     keep = oracle.filter_keep(d["filter_predicated_input"], lambda v: v == 8 or (v & 1))
     assert d["filter_predicated_output"] == keep.tolist()
     assert d["uniquify_output"] == oracle.uniquify(d["uniquify_input"]).tolist()

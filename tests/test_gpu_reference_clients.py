@@ -157,14 +157,15 @@ def test_reference_headers_as_a_partitioned_job_of_one_on_rccl(refc, oracle, gol
     assert refc.pr_job_refused(dev(Ap), dev(Aj), dev(Ax), p, ea.Context.unique_id())
 
 
-@pytest.mark.parametrize("algo", ["kcore", "ppr", "color"])
+@pytest.mark.parametrize("algo", ["kcore", "ppr", "color", "spmv"])
 def test_reference_neighbour_harnesses(algo):
     """Beyond the hot path's three clients: the reference's kcore, ppr and color example harnesses (and
     their algorithm headers), compiled in place and unmodified against include/gunrock, checked by
     the reference's OWN CPU implementations inside the harness (kcore_cpu.hxx, ppr_cpu.hxx).  They
     lean on the operators next to advance -- predicated filters whose predicates have side effects
     (kcore.hxx:150-175, ppr.hxx:120-145), parallel_for, batch over host threads, frontier
-    sequence() -- SURVEY.md 8(f) rows f2 / f3."""
+    sequence() -- SURVEY.md 8(f) rows f2 / f3; spmv runs its PULL form, i.e.
+    operators::neighborreduce (spmv.hxx:107-128)."""
     import subprocess
     repo = os.path.dirname(os.path.dirname(GOLDEN_DIR))
     exe = os.path.join(repo, "oracle", "_ref", "ref_" + algo)
