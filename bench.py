@@ -391,6 +391,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+        runner.close()
         dist.destroy_process_group()
 
 

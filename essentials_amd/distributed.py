@@ -696,6 +696,18 @@ class PartitionedRunner:
                 out["single_gpu_check_error"] = repr(e)
         return out
 
+    def close(self) -> None:
+        """Release the plan and leave the job (ncclCommDestroy) while the process group still
+        exists -- not during interpreter shutdown."""
+        if self.plan is not None:
+            self.plan.close()
+            self.plan = None
+        try:
+            self.stream.synchronize()
+            self.ctx.detach()
+        except Exception:
+            pass
+
     def _traverse(self, op: int, source: int, labels) -> dict:
         if self.plan is not None:
             with self._torch.cuda.stream(self.stream):
