@@ -54,6 +54,19 @@ def attribute(name):
     return k, client
 
 
+def attribute_all(names):
+    """attribute() over dispatches in launch order; a hub pre-pass (no functor in its template
+    arguments) belongs to the client of the expansion kernel launched right after it."""
+    out = [attribute(n) for n in names]
+    for i, (k, c) in enumerate(out):
+        if k == "classify_hubs_kernel" and c == "-":
+            for k2, c2 in out[i + 1:i + 3]:
+                if k2 == "expand_fused_kernel":
+                    out[i] = (k, c2)
+                    break
+    return out
+
+
 def bench_line(path):
     for line in reversed(open(path).read().splitlines()):
         if line.startswith("{"):
@@ -71,8 +84,7 @@ with open(PRE + "kernel_trace_advance.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "client", "start_ns", "end_ns", "duration_us", "grid_threads", "workgroup",
                 "lds_bytes", "vgpr", "sgpr"])
-    for r in rows:
-        k, c = attribute(r["Kernel_Name"])
+    for r, (k, c) in zip(rows, attribute_all([r["Kernel_Name"] for r in rows])):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         per_kernel[(k, c)][0] += 1
         per_kernel[(k, c)][1] += (e - s) / 1e3
@@ -113,8 +125,11 @@ trace = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
 def pmc(passname):
     table = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.OrderedDict()
-    for r in csv.DictReader(open(one(f"{passname}/**/*counter_collection.csv"))):
-        k, c = attribute(r["Kernel_Name"])
+    raw = list(csv.DictReader(open(one(f"{passname}/**/*counter_collection.csv"))))
+    order = sorted({int(r["Dispatch_Id"]): r["Kernel_Name"] for r in raw}.items())
+    who = dict(zip((d for d, _ in order), attribute_all([n for _, n in order])))
+    for r in raw:
+        k, c = who[int(r["Dispatch_Id"])]
         table[(k, c)][r["Counter_Name"]] += float(r["Counter_Value"])
         d = disp.setdefault(r["Dispatch_Id"], {"kernel": k, "client": c, "counters": {}})
         d["counters"][r["Counter_Name"]] = float(r["Counter_Value"])
