@@ -70,7 +70,8 @@ class _Options(C.Structure):
                 ("frontier_sizing_factor", C.c_float), ("collect_kernel_time", C.c_int32),
                 ("chunk_edges", C.c_int32), ("direction_optimized", C.c_int32),
                 ("do_alpha", C.c_float), ("do_beta", C.c_float),
-                ("chunk_queue_limit", C.c_int32), ("sssp_two_pass", C.c_int32)]
+                ("chunk_queue_limit", C.c_int32), ("sssp_two_pass", C.c_int32),
+                ("call_every_edge", C.c_int32)]
 
 
 class _Stats(C.Structure):
@@ -112,6 +113,7 @@ class Options:
     do_beta: float = 0.0
     chunk_queue_limit: int = 0
     sssp_two_pass: bool = False
+    call_every_edge: bool = False
 
     def _c(self) -> _Options:
         o = _Options()
@@ -127,6 +129,7 @@ class Options:
         o.do_beta = float(self.do_beta)
         o.chunk_queue_limit = int(self.chunk_queue_limit)
         o.sssp_two_pass = int(self.sssp_two_pass)
+        o.call_every_edge = int(self.call_every_edge)
         return o
 
 

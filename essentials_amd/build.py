@@ -50,7 +50,8 @@ def _compile(src, obj, defines=()):
 def build_variant(name: str, defines, only=None, jobs: int | None = None) -> str:
     """Experiment build: essentials_amd/libessentials_amd.<name>.so with extra -D flags
     (loaded when ESSENTIALS_AMD_LIB points at it).  Not part of the product build."""
-    objdir = os.path.join(OBJ, name)
+    # objects outside the tree: the tree is what gpurun snapshots (512 MiB cap)
+    objdir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "essentials_amd_variants", name)
     os.makedirs(objdir, exist_ok=True)
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     todo, objs = [], []

@@ -145,6 +145,8 @@ struct scoped_options {
         ctx.options().chunk_edges = (unsigned)opt->chunk_edges;
       ctx.options().time_kernels = opt->collect_kernel_time != 0;
       ctx.options().chunk_queue_limit = opt->chunk_queue_limit > 0 ? (unsigned long long)opt->chunk_queue_limit : 0ull;
+      if (opt->call_every_edge)
+        ctx.options().settled_filter = false;
     }
     ctx.kernel_clock().reset();
   }

@@ -116,8 +116,29 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
       // a lane's four in-flight edges -- DESIGN.md section 5.)
       return next_level < math::atomic::min(&depth[dst], next_level);
     };
-    operators::advance::execute<lb>(G, E, visit, context);
+    // wide levels (block_mapped's fused form): every vertex that has a depth is settled -- visit()
+    // returns false for it and changes nothing -- so the engine may answer those lookups from LDS
+    // (operators/settled.hxx).  The bitmap is rebuilt from the depths, one small kernel per level.
+    auto ctx = context.get_context(0);
+    const unsigned long long work = E->get_input_frontier()->work_hint();
+    if (lb == load_balance_t::block_mapped && ctx->options().settled_filter &&
+        !ctx->options().holes_layout && work != frontier_t::unknown_work &&
+        work >= ctx->options().settled_min_work) {
+      auto has_depth = [depth] __device__(vertex_t const& v) -> bool {
+        return depth[v] != std::numeric_limits<vertex_t>::max();
+      };
+      {  // part of this level's advance: timed with it when kernels are timed
+        operators::advance::detail::clocked_t clock(*ctx);
+        settled.rebuild((std::size_t)G.get_number_of_vertices(), has_depth, *ctx);
+        clock.stop();
+      }
+      operators::advance::execute<lb>(
+          G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+    } else {
+      operators::advance::execute<lb>(G, E, visit, context);
+    }
   }
+  operators::advance::settled_filter_t<vertex_t> settled;
 };
 
 // ---------------------------------------------------------------------------

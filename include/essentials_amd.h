@@ -109,6 +109,11 @@ typedef struct grx_options {
                                    improved vertex per round (atomic::exch on a stamp); 1 the reference
                                    client's formulation, advance + bypass filter with its racy stamp
                                    test (algorithms/sssp.hxx:110-144).  Same distances either way       */
+  int32_t call_every_edge;      /* grx_bfs push: 0 the search names its settled destinations (vertices that
+                                   have a depth) and the engine skips the functor call for an edge into one
+                                   (gunrock/framework/operators/settled.hxx; wide block_mapped levels);
+                                   1 the functor is called for every edge, which is all the engine can do
+                                   for the unchanged bfs.hxx.  Same depths either way                  */
 } grx_options;
 
 /* What enact() reports (framework/enactor.hxx:243-254 returns ms only; the rest is the

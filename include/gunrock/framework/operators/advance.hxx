@@ -328,7 +328,11 @@ void execute(graph_t& G,
   // wide frontiers: hub pre-pass + ONE kernel that expands tiles and then claims hub chunks
   // dynamically (advance_kernels.hxx: classify_hubs_kernel / expand_fused_kernel)
   const std::size_t fused_from = context.options().fused_min_slots;
-  if (!holes && !dynamic_tiles && fused_from && n_in >= fused_from) {
+  bool use_settled = false;
+  if constexpr (settled_traits<operator_t>::value)
+    use_settled = op.settled.bits && op.settled.limit > 0 && context.options().settled_filter &&
+                  work_bound != ~0ull && work_bound >= context.options().settled_min_work;
+  if (!holes && !dynamic_tiles && ((fused_from && n_in >= fused_from) || use_settled)) {
     // scratch: [8 claim cursors, one 128-B line each | hub mask, one bit per input slot]
     auto* cursors = reinterpret_cast<unsigned long long*>(context.workspace().scratch(
         (8 * k::CLAIM_LINE + (n_in + 63) / 64) * sizeof(unsigned long long)));
@@ -337,10 +341,31 @@ void execute(graph_t& G,
         <<<detail::grid_for(n_in, k::CLASSIFY_TILE, (unsigned)context.compute_units() * 8u), k::ADV_BLOCK,
            0, context.stream()>>>(G, input.data(), n_in, nullptr, chunks, chunk_capacity, hub_threshold,
                                   chunk_edges, mask, cursors, counters);
-    const unsigned fgrid = (unsigned)context.compute_units() * context.options().fused_blocks_per_cu;
-    k::expand_fused_kernel<input_type, output_type><<<fgrid, k::ADV_BLOCK, 0, context.stream()>>>(
-        G, op, input.data(), n_in, nullptr, out_ptr, capacity, counters, chunks, chunk_capacity, mask,
-        cursors);
+    bool expanded = false;
+    if constexpr (settled_traits<operator_t>::value) {
+      // the client named settled destinations: one 1024-thread workgroup per CU with the bitmap
+      // in its LDS (advance_kernels.hxx: expand_settled_kernel)
+      if (use_settled) {
+        auto kernel = k::expand_settled_kernel<input_type, output_type, graph_t, operator_t, vertex_t, edge_t>;
+        const std::size_t lds = (std::size_t)op.settled.limit / 8;
+        static std::atomic<std::size_t> allowed{0};  // per instantiation: the opt-in is sticky
+        if (allowed.load(std::memory_order_relaxed) < lds) {
+          GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(settled_max_ids / 8)));
+          allowed.store(settled_max_ids / 8, std::memory_order_relaxed);
+        }
+        kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
+            G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors);
+        expanded = true;
+      }
+    }
+    if (!expanded) {
+      const unsigned fgrid = (unsigned)context.compute_units() * context.options().fused_blocks_per_cu;
+      k::expand_fused_kernel<input_type, output_type><<<fgrid, k::ADV_BLOCK, 0, context.stream()>>>(
+          G, op, input.data(), n_in, nullptr, out_ptr, capacity, counters, chunks, chunk_capacity, mask,
+          cursors);
+    }
   } else if (holes) {
     k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>
         <<<grid, k::ADV_BLOCK, 0, context.stream()>>>(G, op, input.data(), n_in, out_ptr, capacity,
@@ -372,6 +397,13 @@ void execute(graph_t& G,
     detail::fetch_counters(context);  // waits for the kernels and leaves the counters clean
     context.kernel_clock().collect();
   }
+#ifdef GRX_SETTLED_STATS
+  if (use_settled) {
+    const unsigned long long* m = context.workspace().mirror();
+    std::fprintf(stderr, "[settled] slots %zu work %llu: rounds %llu, predicate tests %llu, functor calls %llu "
+                 "carrying %llu edges\n", n_in, work_bound, m[14], m[13], m[10], m[11]);
+  }
+#endif
 }
 
 /**

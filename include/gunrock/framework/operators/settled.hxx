@@ -1,0 +1,129 @@
+/**
+ * @file settled.hxx
+ * @brief "Settled destinations": an optional, one-sided hint a client may attach to its advance
+ * functor (engine extension; the reference has no counterpart -- its advance calls the functor for
+ * every edge, framework/operators/advance/block_mapped.hxx:30-147).
+ *
+ * Contract.  A destination v is SETTLED when the client's functor is known to return false for it
+ * and to change nothing (BFS: v already has a depth).  The client names settled destinations in
+ * two forms, either of which may be stale or partial -- "not settled" promises nothing:
+ *   - a bitmap, one bit per vertex id below `limit` (settled_filter_t), and / or
+ *   - a PURE device predicate `settled(v)` (plain loads, no side effects),
+ * and the engine is then free -- not obliged -- to skip the functor call for an edge whose
+ * destination is settled.
+ *
+ * Why.  A wide level is bound by what happens per edge inside the opaque functor: a label lookup
+ * (one L2 request per edge) and, where it passes, a memory-side atomic whose round trip every lane
+ * of the wavefront waits for; the four calls a lane has in flight are serialised by the compiler
+ * (DESIGN.md section 5).  With the hint, expand_settled_kernel
+ *   1. answers the lookups of the low -- on power-law graphs: the hot -- ids from a copy of the
+ *      bitmap in LDS (tools/lds_filter_probe.hip: 175 -> 340 G lookups/s on R-MAT-22 ids),
+ *   2. evaluates the predicate for the rest with four independent loads in flight per lane,
+ *   3. packs the surviving edges of a wavefront and calls the functor on full groups of 64 only.
+ *
+ *   operators::advance::settled_filter_t<vertex_t> settled;          // enactor member
+ *   auto has_depth = [depth] __device__(vertex_t v) { return depth[v] != unvisited; };
+ *   settled.rebuild(n_vertices, has_depth, ctx);
+ *   operators::advance::execute<lb>(
+ *       G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+ *
+ * Schedules other than block_mapped's wide-level form call the functor for every edge as before.
+ */
+#pragma once
+
+#include <cstddef>
+#include <type_traits>
+
+#include <gunrock/hip/context.hxx>
+
+namespace gunrock {
+namespace operators {
+namespace advance {
+
+/// Ids covered by the LDS filter: 96 KB of bits, what fits beside the kernel's own LDS in a CU's
+/// 160 KB.
+constexpr std::size_t settled_max_ids = std::size_t(96) << 13;
+
+template <typename vertex_t>
+struct settled_view_t {
+  const unsigned* bits = nullptr;  ///< bit v of word v / 32, 16-byte aligned
+  vertex_t limit = 0;              ///< ids >= limit are not covered; a multiple of 128
+};
+
+/// The predicate of a client that has a bitmap only.
+struct settled_never_t {
+  template <typename vertex_t>
+  __host__ __device__ __forceinline__ bool operator()(vertex_t const&) const {
+    return false;
+  }
+};
+
+/// A functor with a settled view and predicate attached.  Callable like the functor itself.
+template <typename op_t, typename pred_t, typename vertex_t>
+struct settled_op_t {
+  op_t op;
+  settled_view_t<vertex_t> settled;
+  pred_t is_settled;
+  template <typename... args_t>
+  __host__ __device__ __forceinline__ bool operator()(args_t const&... args) const {
+    return op(args...);
+  }
+};
+
+template <typename op_t, typename vertex_t, typename pred_t = settled_never_t>
+settled_op_t<op_t, pred_t, vertex_t> with_settled(op_t op,
+                                                  settled_view_t<vertex_t> view,
+                                                  pred_t pred = pred_t()) {
+  return settled_op_t<op_t, pred_t, vertex_t>{op, view, pred};
+}
+
+template <typename T>
+struct settled_traits : std::false_type {};
+template <typename op_t, typename pred_t, typename vertex_t>
+struct settled_traits<settled_op_t<op_t, pred_t, vertex_t>> : std::true_type {};
+
+namespace detail_settled {
+/// One wavefront per 64 ids: the ballot of the predicate IS the two bitmap words.
+template <typename vertex_t, typename pred_t>
+__global__ void __launch_bounds__(256)
+    rebuild_kernel(unsigned long long* words, vertex_t limit, vertex_t n_vertices, pred_t pred) {
+  const std::size_t stride = (std::size_t)gridDim.x * 256;
+  for (std::size_t i = (std::size_t)blockIdx.x * 256 + threadIdx.x; i < (std::size_t)limit; i += stride) {
+    const bool set = i < (std::size_t)n_vertices && pred((vertex_t)i);
+    const unsigned long long word = __ballot(set);
+    if ((threadIdx.x & 63) == 0)
+      words[i / 64] = word;
+  }
+}
+}  // namespace detail_settled
+
+/// Owner of the bitmap.  rebuild() is one small kernel (reads `limit` labels, writes limit / 8
+/// bytes) on the context's stream; call it before an advance that is worth it (a wide frontier).
+template <typename vertex_t>
+class settled_filter_t {
+ public:
+  template <typename pred_t>
+  void rebuild(std::size_t n_vertices, pred_t pred, gcuda::standard_context_t& context) {
+    std::size_t ids = n_vertices < settled_max_ids ? n_vertices : settled_max_ids;
+    ids = (ids + 127) / 128 * 128;  // whole 16-byte groups; bits of ids >= n_vertices stay clear
+    if (words_.size() < ids / 64)
+      words_.resize(ids / 64);
+    limit_ = (vertex_t)ids;
+    const unsigned grid = (unsigned)((ids + 255) / 256 < 1024 ? (ids + 255) / 256 : 1024);
+    detail_settled::rebuild_kernel<<<grid, 256, 0, context.stream()>>>(words_.data(), limit_,
+                                                                      (vertex_t)n_vertices, pred);
+    GRX_HIP_CHECK(hipGetLastError());
+  }
+  settled_view_t<vertex_t> view() const {
+    return settled_view_t<vertex_t>{reinterpret_cast<const unsigned*>(words_.data()), limit_};
+  }
+  void clear() { limit_ = 0; }
+
+ private:
+  hip::device_array_t<unsigned long long> words_;
+  vertex_t limit_ = 0;
+};
+
+}  // namespace advance
+}  // namespace operators
+}  // namespace gunrock

@@ -180,6 +180,11 @@ struct operator_options_t {
   std::size_t fused_min_slots = 32768;
   /// Persistent workgroups per CU of the fused kernel (what is resident at its register use).
   unsigned fused_blocks_per_cu = 6;
+  /// Honour the settled-destination hint a client attached to its functor (operators/settled.hxx)
+  /// on wide block_mapped levels; false: the functor is called for every edge.
+  bool settled_filter = true;
+  /// ... from this many edges of work on (a level of a few hubs is as wide as one of 1 M slots).
+  unsigned long long settled_min_work = 1ull << 20;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -287,6 +292,10 @@ class standard_context_t {
       options_.fused_min_slots = (std::size_t)std::atoll(e);
     if (const char* e = std::getenv("GRX_FUSED_BLOCKS_PER_CU"))
       options_.fused_blocks_per_cu = (unsigned)std::atoi(e);
+    if (const char* e = std::getenv("GRX_SETTLED_FILTER"))
+      options_.settled_filter = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GRX_SETTLED_MIN_WORK"))
+      options_.settled_min_work = (unsigned long long)std::atoll(e);
     if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))
       options_.chunk_queue_limit = (unsigned long long)std::atoll(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));

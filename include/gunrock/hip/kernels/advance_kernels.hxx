@@ -40,6 +40,7 @@
 #pragma once
 
 #include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/framework/operators/settled.hxx>
 #include <gunrock/hip/primitives.hxx>
 #include <gunrock/util/type_limits.hxx>
 
@@ -86,6 +87,7 @@ struct wave_queue_t {
   unsigned fill;            // wave-uniform
   unsigned long long work;  // per lane: sum of degrees of the neighbours this lane emitted
   int cursor = C_OUT;       // counter slot that hands out positions of the destination list
+  unsigned cap = ADV_WQCAP; // entries behind q
 
   __device__ __forceinline__ void flush(vertex_t* out, std::size_t capacity,
                                         unsigned long long* counters) {
@@ -137,7 +139,7 @@ struct wave_queue_t {
     unsigned long long m = __ballot(keep);
     if (m == 0)
       return;
-    if (fill + wave_size > (unsigned)ADV_WQCAP)
+    if (fill + wave_size > cap)
       flush_summing(out, capacity, counters, degree_of);
     if (keep)
       q[fill + rank_in_mask(m)] = value;
@@ -150,7 +152,7 @@ struct wave_queue_t {
     unsigned long long m = __ballot(keep);
     if (m == 0)
       return;
-    if (fill + wave_size > (unsigned)ADV_WQCAP)
+    if (fill + wave_size > cap)
       flush(out, capacity, counters);
     if (keep) {
       q[fill + rank_in_mask(m)] = value;
@@ -162,7 +164,7 @@ struct wave_queue_t {
 
 /// Retire a workgroup: drain its four wavefront queues with ONE cursor atomic and
 /// publish the degree sum of everything it emitted.  Contains barriers.
-template <typename vertex_t>
+template <int WAVES = ADV_WAVES, typename vertex_t>
 __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned* s_counts,
                                             unsigned long long* s_base, vertex_t* out,
                                             std::size_t capacity, unsigned long long* counters) {
@@ -178,7 +180,7 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
   if (threadIdx.x == 0) {
     unsigned total = 0;
 #pragma unroll
-    for (int w = 0; w < ADV_WAVES; ++w)
+    for (int w = 0; w < WAVES; ++w)
       total += s_counts[w];
     *s_base = total ? atomicAdd(&counters[wq.cursor], (unsigned long long)total) : 0ull;
   }
@@ -199,7 +201,7 @@ __device__ __forceinline__ void drain_block(wave_queue_t<vertex_t>& wq, unsigned
 
 /// drain_block for queues filled with push_deferred: the degrees of the leftover entries are
 /// looked up first.
-template <typename vertex_t, typename degree_f>
+template <int WAVES = ADV_WAVES, typename vertex_t, typename degree_f>
 __device__ __forceinline__ void drain_block_summing(wave_queue_t<vertex_t>& wq, unsigned* s_counts,
                                                     unsigned long long* s_base, vertex_t* out,
                                                     std::size_t capacity,
@@ -207,7 +209,7 @@ __device__ __forceinline__ void drain_block_summing(wave_queue_t<vertex_t>& wq, 
                                                     degree_f degree_of) {
   for (unsigned j = lane_id(); j < wq.fill; j += wave_size)
     wq.work += degree_of(wq.q[j]);
-  drain_block(wq, s_counts, s_base, out, capacity, counters);
+  drain_block<WAVES>(wq, s_counts, s_base, out, capacity, counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -774,6 +776,304 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   }
   if constexpr (HAS_OUT)
     drain_block_summing(wq, s_counts, &s_base, output, capacity, counters, degree_of);
+}
+
+// ---------------------------------------------------------------------------
+// Wide levels of a client that named its settled destinations (operators/settled.hxx): the work
+// split of expand_fused_kernel (tiles with hub slots masked out, then hub chunks claimed
+// dynamically) with
+//  - ONE 1024-thread workgroup per CU whose dynamic LDS holds the settled bitmap (96 KB = 768 K
+//    ids): an edge whose destination has its bit set costs no memory request at all;
+//  - the client's pure predicate evaluated for the other edges, four independent loads in flight
+//    per lane, while the column loads of the next four are already under way (inside the functor the same test is a dependent load in front of an atomic, and the
+//    four calls of a lane are serialised);
+//  - the surviving edges packed per wavefront (LDS, 12 B each) and the functor called on full
+//    groups of 64: its memory-side atomics are waited for once per 64 SURVIVORS, not once per 64
+//    edges;
+//  - every wavefront on its own: 64-slot tiles scanned in the wave, batches of hub chunks claimed
+//    per wave; the sixteen waves meet at two barriers only (bitmap loaded, queues drained).
+// ---------------------------------------------------------------------------
+#ifndef GRX_SET_BLOCK
+#define GRX_SET_BLOCK 1024
+#endif
+constexpr int SET_BLOCK = GRX_SET_BLOCK;
+constexpr int SET_WAVES = SET_BLOCK / wave_size;  // 16
+constexpr int SET_WQCAP = 256;                    // output queue entries per wavefront
+constexpr int SET_PENDING = 2 * wave_size;        // surviving edges a wavefront may hold
+constexpr int SET_UNROLL = 4;                     // edges per lane and round
+
+template <typename vertex_t, typename edge_t>
+struct pending_edge_t {
+  vertex_t source;
+  vertex_t neighbor;
+  edge_t edge;
+};
+
+template <advance_io_type_t IN,
+          advance_io_type_t OUT,
+          typename graph_t,
+          typename op_t,
+          typename vertex_t,
+          typename edge_t>
+__global__ void __launch_bounds__(SET_BLOCK)
+    expand_settled_kernel(graph_t G,
+                          op_t op,
+                          const vertex_t* __restrict__ input,
+                          std::size_t n_in,
+                          vertex_t* __restrict__ output,
+                          std::size_t capacity,
+                          unsigned long long* counters,
+                          const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
+                          unsigned long long chunk_capacity,
+                          const unsigned long long* __restrict__ hub_mask,
+                          unsigned long long* __restrict__ claim_cursors) {
+  constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  using pending_t = pending_edge_t<vertex_t, edge_t>;
+  extern __shared__ unsigned s_settled[];  // op.settled.limit bits
+  __shared__ vertex_t s_vertex[SET_BLOCK];
+  __shared__ edge_t s_first[SET_BLOCK];
+  __shared__ unsigned s_scan[SET_BLOCK];
+  __shared__ unsigned s_counts[SET_WAVES];
+  __shared__ unsigned long long s_base;
+  __shared__ vertex_t s_queue[HAS_OUT ? SET_WAVES * SET_WQCAP : 1];
+  __shared__ pending_t s_pending[SET_WAVES * SET_PENDING];
+
+  const int tid = threadIdx.x;
+  const int wave = tid / wave_size;
+  const int lane = lane_id();
+  const vertex_t limit = op.settled.limit;
+  {
+    const unsigned words = (unsigned)limit / 32u;  // a multiple of 4
+    const uint4* src = reinterpret_cast<const uint4*>(op.settled.bits);
+    uint4* dst = reinterpret_cast<uint4*>(s_settled);
+    for (unsigned w = tid; w < words / 4u; w += SET_BLOCK)
+      dst[w] = src[w];
+  }
+  __syncthreads();
+  auto in_bitmap = [&](vertex_t n) -> bool {  // an unconditional LDS read: no branch, no wait per edge
+    const unsigned at = (unsigned)n < (unsigned)limit ? (unsigned)n : 0u;
+    return (unsigned)n < (unsigned)limit && ((s_settled[at >> 5] >> (at & 31u)) & 1u);
+  };
+
+  wave_queue_t<vertex_t> wq{s_queue + (HAS_OUT ? wave * SET_WQCAP : 0), 0u, 0ull};
+  wq.cap = SET_WQCAP;
+  auto degree_of = [&G](vertex_t x) -> unsigned { return (unsigned)G.get_number_of_neighbors(x); };
+  vertex_t* const w_vertex = s_vertex + wave * wave_size;
+  edge_t* const w_first = s_first + wave * wave_size;
+  unsigned* const w_scan = s_scan + wave * wave_size;
+  pending_t* const w_pending = s_pending + wave * SET_PENDING;
+  unsigned n_pending = 0;  // wave-uniform
+
+  // the functor, on the top `count` (<= 64) pending edges of this wavefront
+#ifdef GRX_SETTLED_STATS
+  unsigned long long st_calls = 0, st_survivors = 0, st_tested = 0, st_rounds = 0;
+#endif
+  auto call = [&](unsigned count) __attribute__((always_inline)) {
+#ifdef GRX_SETTLED_STATS
+    st_calls += 1;
+    st_survivors += count;
+#endif
+    n_pending -= count;
+    bool keep = false;
+    vertex_t nbr = 0;
+    if ((unsigned)lane < count) {
+      const pending_t e = w_pending[n_pending + lane];
+      nbr = e.neighbor;
+      keep = op(e.source, e.neighbor, e.edge, G.get_edge_weight(e.edge));
+    }
+    if constexpr (HAS_OUT)
+      wq.push_deferred(keep, nbr, output, capacity, counters, degree_of);
+  };
+  // one round = four edges per lane: bitmap, predicate (independent loads), pack, call on full
+  // groups
+  auto consider = [&](const vertex_t (&src)[SET_UNROLL], const vertex_t (&nbr)[SET_UNROLL],
+                      const edge_t (&eid)[SET_UNROLL], const bool (&live)[SET_UNROLL])
+      __attribute__((always_inline)) {
+    bool open[SET_UNROLL];
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+      open[k] = !in_bitmap(nbr[k]);
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+      open[k] = open[k] && live[k];
+    // The predicate is evaluated by ALL lanes, unconditionally: behind a branch each of its loads
+    // would be waited for in turn.  Lanes with nothing to ask look at vertex 0 (one hot line).
+    bool done[SET_UNROLL];
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+#if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 1  // timing experiment: columns + LDS only
+      done[k] = true;
+#else
+      done[k] = (bool)op.is_settled(open[k] ? nbr[k] : vertex_t(0));
+#endif
+    __builtin_amdgcn_sched_barrier(0);  // all the loads first, then their consumers
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+      done[k] = done[k] || !open[k];
+#if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 2  // timing experiment: lookups, no functor
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+      done[k] = done[k] || nbr[k] >= 0;
+#endif
+#ifdef GRX_SETTLED_STATS
+    st_rounds += 1;
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k)
+      st_tested += __popcll(__ballot(open[k]));
+#endif
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k) {
+      const bool survive = !done[k];
+      const unsigned long long m = __ballot(survive);
+      if (m == 0)
+        continue;
+      if (survive)
+        w_pending[n_pending + rank_in_mask(m)] = pending_t{src[k], nbr[k], eid[k]};
+      n_pending += (unsigned)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (n_pending >= (unsigned)wave_size)
+        call(wave_size);
+    }
+  };
+  // Rounds pass through a delay line of one: the column loads of round r + 1 are issued before
+  // round r is considered, so they fly together with r's predicate loads.
+  vertex_t p_src[SET_UNROLL], p_nbr[SET_UNROLL];
+  edge_t p_eid[SET_UNROLL];
+  bool p_live[SET_UNROLL];
+  bool have_prev = false;  // wave-uniform
+  auto submit = [&](const vertex_t (&src)[SET_UNROLL], const vertex_t (&nbr)[SET_UNROLL],
+                    const edge_t (&eid)[SET_UNROLL], const bool (&live)[SET_UNROLL])
+      __attribute__((always_inline)) {
+    if (have_prev)
+      consider(p_src, p_nbr, p_eid, p_live);
+#pragma unroll
+    for (int k = 0; k < SET_UNROLL; ++k) {
+      p_src[k] = src[k];
+      p_nbr[k] = nbr[k];
+      p_eid[k] = eid[k];
+      p_live[k] = live[k];
+    }
+    have_prev = true;
+  };
+
+  // ---- phase 1: 64-slot tiles, one per wavefront and step; hub slots are left to phase 2 ----------
+  const unsigned long long n_tiles = (n_in + wave_size - 1) / wave_size;
+  const unsigned long long wave_stride = (unsigned long long)gridDim.x * SET_WAVES;
+  auto fetch_slot = [&](unsigned long long t, vertex_t& v, edge_t& first, edge_t& last) {
+    v = gunrock::numeric_limits<vertex_t>::invalid();
+    first = last = 0;
+    const std::size_t idx = (std::size_t)t * wave_size + lane;
+    if (t < n_tiles && idx < n_in) {
+      const vertex_t x = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
+      const bool hub = (hub_mask[t] >> lane) & 1ull;
+      if (util::limits::is_valid(x) && !hub) {
+        v = x;
+        first = G.get_starting_edge(x);
+        last = G.get_starting_edge(x + 1);
+      }
+    }
+  };
+  unsigned long long tile = (unsigned long long)wave * gridDim.x + blockIdx.x;
+  vertex_t v, v1;
+  edge_t first, last, first1, last1;
+  fetch_slot(tile, v, first, last);
+  while (tile < n_tiles) {  // wave-uniform
+    fetch_slot(tile + wave_stride, v1, first1, last1);
+    const unsigned deg = (unsigned)(last - first);
+    const unsigned incl = wave_inclusive_sum(deg);
+    const unsigned total = __shfl(incl, wave_size - 1, wave_size);
+    w_vertex[lane] = v;
+    w_first[lane] = first;
+    w_scan[lane] = incl - deg;
+    __builtin_amdgcn_wave_barrier();  // LDS is in order within a wavefront; pin the compiler too
+    for (unsigned i0 = 0; i0 < total; i0 += wave_size * SET_UNROLL) {
+      vertex_t src[SET_UNROLL], nbr[SET_UNROLL];
+      edge_t eid[SET_UNROLL];
+      bool live[SET_UNROLL];
+#pragma unroll
+      for (int k = 0; k < SET_UNROLL; ++k) {
+        const unsigned i = i0 + k * wave_size + lane;
+        live[k] = i < total;
+        src[k] = nbr[k] = 0;
+        eid[k] = 0;
+        if (live[k]) {
+          const int slot = rightmost_le(w_scan, i, wave_size);
+          src[k] = w_vertex[slot];
+          eid[k] = w_first[slot] + (edge_t)(i - w_scan[slot]);
+          nbr[k] = G.get_destination_vertex(eid[k]);
+        }
+      }
+      submit(src, nbr, eid, live);
+    }
+    __builtin_amdgcn_wave_barrier();  // the tile arrays are rewritten; rounds carry their sources
+    tile += wave_stride;
+    v = v1;
+    first = first1;
+    last = last1;
+  }
+
+  // ---- phase 2: hub chunks, a batch per claim and wavefront --------------------------------------
+  unsigned long long n_chunks =
+      __hip_atomic_load(&counters[C_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n_chunks > chunk_capacity)
+    n_chunks = chunk_capacity;
+  if (n_chunks) {  // grid-uniform
+    const unsigned long long n_batches = (n_chunks + CLAIM_BATCH - 1) / CLAIM_BATCH;
+    const unsigned pools = gridDim.x < 8u ? gridDim.x : 8u;
+    unsigned pool = blockIdx.x % pools;  // lane 0's; the other lanes only receive batches
+    unsigned tried = 0;
+    unsigned long long pending = 0;
+    if (lane == 0)
+      pending = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull);
+    for (;;) {
+      unsigned long long batch = 0;
+      if (lane == 0) {
+        batch = pending * pools + pool;
+        while (batch >= n_batches && ++tried < pools) {  // own pool exhausted: help the next one
+          pool = (pool + 1) % pools;
+          batch = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull) * pools + pool;
+        }
+        if (batch < n_batches)  // request the NEXT batch now; its round trip hides behind this one
+          pending = atomicAdd(&claim_cursors[pool * CLAIM_LINE], 1ull);
+      }
+      batch = __shfl(batch, 0, wave_size);
+      if (batch >= n_batches)
+        break;
+      const unsigned long long c0 = batch * CLAIM_BATCH;
+      const unsigned long long c1 = c0 + CLAIM_BATCH < n_chunks ? c0 + CLAIM_BATCH : n_chunks;
+      for (unsigned long long c = c0; c < c1; ++c) {
+        const chunk_t<vertex_t, edge_t> d = chunks[c];
+        for (int j0 = 0; j0 < d.count; j0 += wave_size * SET_UNROLL) {
+          vertex_t src[SET_UNROLL], nbr[SET_UNROLL];
+          edge_t eid[SET_UNROLL];
+          bool live[SET_UNROLL];
+#pragma unroll
+          for (int k = 0; k < SET_UNROLL; ++k) {
+            const int j = j0 + k * wave_size + lane;
+            live[k] = j < d.count;
+            src[k] = d.source;
+            eid[k] = d.first + (edge_t)j;
+            nbr[k] = live[k] ? G.get_destination_vertex(eid[k]) : vertex_t(0);
+          }
+          submit(src, nbr, eid, live);
+        }
+      }
+    }
+  }
+  if (have_prev)
+    consider(p_src, p_nbr, p_eid, p_live);
+#ifdef GRX_SETTLED_STATS
+  if (lane == 0) {  // diagnostic build: functor calls, edges they carried, predicate tests, rounds
+    atomicAdd(&counters[10], st_calls);
+    atomicAdd(&counters[11], st_survivors);
+    atomicAdd(&counters[13], st_tested);
+    atomicAdd(&counters[14], st_rounds);
+  }
+#endif
+  if (n_pending)  // wave-uniform; fewer than 64 are left
+    call(n_pending);
+  if constexpr (HAS_OUT)
+    drain_block_summing<SET_WAVES>(wq, s_counts, &s_base, output, capacity, counters, degree_of);
 }
 
 // ---------------------------------------------------------------------------

@@ -245,6 +245,84 @@ int main(int argc, char** argv) {
   run_schedule(std::integral_constant<lbt, lbt::bucketing>(), "bucketing");
   run_schedule(std::integral_constant<lbt, lbt::work_stealing>(), "work_stealing");
 
+  // ---- settled destinations (operators/settled.hxx): bitmap + pure predicate in front of the functor
+  {
+    auto* ctx0 = mc->get_context(0);
+    const auto saved = ctx0->options();
+    ctx0->options().settled_min_work = 1;  // take the wide-level form for this small frontier too
+    frontier_t fin, fout;
+    for (int v : fin_h) fin.push_back(v);
+    unsigned long long work = 0;  // the form is chosen by the frontier's known work
+    for (int v : fin_h)
+      if (v >= 0) work += (unsigned long long)(hg.ap[v + 1] - hg.ap[v]);
+    fin.set_work_hint(work);
+    hip::device_array_t<int> hits(hg.n);
+    hits.zero();
+    int* ph = hits.data();
+    hip::device_array_t<edge_t> segments;
+    auto op = [ph] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                       weight_t const& w) -> bool {
+      math::atomic::add(&ph[d], 1);
+      return (s + d) % 2 == 0;
+    };
+    // the client names d % 3 == 0 through the bitmap and d % 5 == 0 through the predicate
+    operators::advance::settled_filter_t<vertex_t> named;
+    named.rebuild((std::size_t)hg.n, [] __device__(vertex_t v) { return v % 3 == 0; }, *ctx0);
+    auto by_rule = [] __host__ __device__(vertex_t const& v) -> bool { return v % 5 == 0; };
+    auto hinted = operators::advance::with_settled(op, named.view(), by_rule);
+#ifdef GRX_ADVANCE_LB_OVERRIDE  // another schedule runs: it has no LDS filter and must ignore the hint
+    auto is_named = [](int) { return false; };
+#else
+    auto is_named = [](int d) { return d % 3 == 0 || d % 5 == 0; };
+#endif
+    constexpr auto lb = operators::load_balance_t::block_mapped;
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::vertices>(G, hinted, &fin, &fout, segments, *mc);
+    auto out = fout.to_host();
+    std::multiset<int> got(out.begin(), out.end()), want;
+    got.erase(-1);
+    for (int d : want_out)
+      if (!is_named(d)) want.insert(d);
+    auto hh = hits.to_host();
+    bool ok = true;
+    // contract: exactly once per edge into a destination that was not named, at most once per edge
+    // otherwise; THIS kernel skips every named destination, which also proves it ran
+    for (int v = 0; v < hg.n; ++v) ok &= is_named(v) ? hh[v] == 0 : hh[v] == want_hits[v];
+    if (!(ok && got == want)) { std::printf("FAIL settled hint (vertices->vertices)\n"); ++failures; }
+    {
+      std::vector<int> sorted_out(got.begin(), got.end());
+      dump_array("advance_settled_output", sorted_out);
+      dump_array("advance_settled_calls_per_destination", hh);
+    }
+    hits.zero();
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::none>(G, hinted, &fin, &fout, segments, *mc);
+    hh = hits.to_host();
+    ok = true;
+    for (int v = 0; v < hg.n; ++v) ok &= is_named(v) ? hh[v] == 0 : hh[v] == want_hits[v];
+    if (!ok) { std::printf("FAIL settled hint (vertices->none)\n"); ++failures; }
+    // switched off, or on a schedule without the LDS filter, the functor sees every edge
+    ctx0->options().settled_filter = false;
+    hits.zero();
+    operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::none>(G, hinted, &fin, &fout, segments, *mc);
+    hh = hits.to_host();
+    ok = true;
+    for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
+    ctx0->options().settled_filter = true;
+    hits.zero();
+    operators::advance::execute<operators::load_balance_t::merge_path, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::vertices,
+                                operators::advance_io_type_t::none>(G, hinted, &fin, &fout, segments, *mc);
+    hh = hits.to_host();
+    for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
+    if (!ok) { std::printf("FAIL settled hint ignored where it must be\n"); ++failures; }
+    ctx0->options() = saved;
+  }
+
   // ---- neighborreduce: per-vertex reduction over out-edges (reference neighborreduce.hxx:55-101) ---
   {
     using problem_type = toy_problem_t<graph_t>;

@@ -67,6 +67,18 @@ def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
     for name in schedules:
         assert d["advance_output_" + name] == want, name
         assert d["advance_calls_per_destination_" + name] == calls.tolist(), name
+    # settled hint (d % 3 == 0 by bitmap, d % 5 == 0 by predicate): the functor sees the other edges
+    named = (np.arange(n) % 3 == 0) | (np.arange(n) % 5 == 0)
+    calls[:] = 0
+
+    def op_unnamed(s, dst, e, w):
+        if named[dst]:
+            return False
+        calls[dst] += 1
+        return (s + dst) % 2 == 0
+    want = oracle.advance(Ap, Aj, Ax, frontier, op_unnamed)
+    assert d["advance_settled_output"] == np.sort(want[want != -1]).tolist()
+    assert d["advance_settled_calls_per_destination"] == calls.tolist()
     # neighborreduce: y[v] = sum over out-edges of w * x[dst], x[v] = v % 7 (exact in float)
     x = (np.arange(n) % 7).astype(np.float64)
     want_y = np.add.reduceat(np.concatenate([Ax * x[Aj], [0.0]]), np.minimum(Ap[:-1], len(Aj)))

@@ -325,6 +325,26 @@ def test_bfs_sssp_rmat18_against_oracle(ea, ctx, oracle, lb):
     assert (host(w).view(np.uint32) == want.view(np.uint32)).all(), lb
 
 
+@pytest.mark.parametrize("scale,limit", [(16, 0), (20, 0), (20, 5)])
+def test_bfs_settled_hint_changes_nothing(ea, ctx, oracle, scale, limit):
+    """The search names its settled destinations on wide levels (operators/settled.hxx, the default)
+    or calls the functor for every edge (call_every_edge): same depths, same counts, same frontier
+    lengths level by level -- against the oracle and against each other, also with the hub chunk
+    queue capped (hubs expanded in their tiles)."""
+    g = ea.Graph.rmat(ctx, scale, 16, seed=3, weight_seed=0)
+    Ap, Aj, _ = g.to_host()
+    deg = np.diff(Ap)
+    rng = np.random.default_rng(scale + SEED_OFFSET)
+    for s in [0] + rng.choice(np.flatnonzero(deg > 0), 4).tolist():
+        d1, st1 = ea.bfs(ctx, g, int(s), options=ea.Options(chunk_queue_limit=limit))
+        d0, st0 = ea.bfs(ctx, g, int(s), options=ea.Options(call_every_edge=True, chunk_queue_limit=limit))
+        want, _ = oracle.bfs_heap(Ap, Aj, int(s))
+        assert (host(d1) == want).all() and (host(d0) == want).all(), s
+        assert st1.frontier_slots == st0.frontier_slots, s
+        assert st1.edges_traversed == st0.edges_traversed == int(deg[want != INF_I].sum())
+        assert st1.vertices_reached == st0.vertices_reached == int((want != INF_I).sum())
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json's full size (RMAT-22): size-independent properties
 # ---------------------------------------------------------------------------
@@ -332,6 +352,9 @@ def test_bfs_rmat22_properties(ea, ctx, torch):
     g = ea.Graph.rmat(ctx, 22, 16, seed=1)
     assert g.n_rows == 1 << 22 and 130_000_000 < g.nnz < 2**27
     d0, st0 = ea.bfs(ctx, g, 0)
+    # (0) with and without the settled-destination hint on the wide levels
+    d, st = ea.bfs(ctx, g, 0, options=ea.Options(call_every_edge=True))
+    assert torch.equal(d, d0) and st.frontier_slots == st0.frontier_slots
     # (1) every schedule produces the same labels
     for lb in ("merge_path", "bucketing", "work_stealing"):
         d, st = ea.bfs(ctx, g, 0, options=ea.Options(load_balance=ea.LoadBalance[lb]))

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Kernel sequence of the LAST traversal in a `rocprofv3 --kernel-trace` of tools/level_profile.py:
+name (template arguments cut) and duration of every dispatch, in launch order."""
+import csv, glob, sys
+path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"].split("<")[0].split("(")[0].split("::")[-1] for r in rows]
+# last traversal = after the last reset (for_each_index... of the depth fill): find last 'reach_stats'
+ends = [i for i, n in enumerate(names) if "reach_stats" in n]
+lo = ends[-2] + 1 if len(ends) >= 2 else 0
+hi = ends[-1] + 1 if ends else len(rows)
+tot = 0.0
+for r, n in zip(rows[lo:hi], names[lo:hi]):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += us
+    print(f"{n:34s} {us:9.1f} us  grid {r.get('Grid_Size','?'):>8s} wg {r.get('Workgroup_Size','?')}")
+print("sum", round(tot, 1), "us")
