@@ -171,17 +171,33 @@ int with_load_balance(int lb, F&& f) {
 
 /// One pass over the labels: reached vertices, the sum of their out-degrees and the source's own
 /// degree land in three of the context's device counters (zero between operators).
+constexpr int REACH_BLOCK = 1024;
 template <typename label_t>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(REACH_BLOCK)
     reach_stats_kernel(const label_t* labels, label_t unreached, const int32_t* ap, int64_t n,
                        int32_t source, unsigned long long* counters) {
-  __shared__ unsigned long long s_v[256 / gunrock::hip::wave_size], s_e[256 / gunrock::hip::wave_size];
+  constexpr int WAVES = REACH_BLOCK / gunrock::hip::wave_size;
+  __shared__ unsigned long long s_v[WAVES], s_e[WAVES];
   unsigned long long v = 0, e = 0;
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    if (labels[i] != unreached) {
-      ++v;
-      e += (unsigned long long)(ap[i + 1] - ap[i]);
+  const int64_t stride = (int64_t)gridDim.x * REACH_BLOCK;
+  // four independent label / offset reads in flight per thread
+  for (int64_t i0 = blockIdx.x * (int64_t)REACH_BLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    label_t l[4];
+    int32_t lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      const bool in = i < n;
+      l[k] = in ? labels[i] : unreached;
+      lo[k] = in ? ap[i] : 0;
+      hi[k] = in ? ap[i + 1] : 0;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (l[k] != unreached) {
+        ++v;
+        e += (unsigned long long)(hi[k] - lo[k]);
+      }
   }
   v = gunrock::hip::wave_sum(v);
   e = gunrock::hip::wave_sum(e);
@@ -192,7 +208,7 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long tv = 0, te = 0;
-    for (int k = 0; k < 256 / gunrock::hip::wave_size; ++k) {
+    for (int k = 0; k < WAVES; ++k) {
       tv += s_v[k];
       te += s_e[k];
     }
@@ -213,10 +229,11 @@ long long reach_stats(grx_graph_s* g, const label_t* d_labels, label_t unreached
   if (!stats)
     return 0;
   const int64_t n = g->n_rows;
-  // one workgroup per CU: the three result words take one atomic each per workgroup, and a single
-  // device word retires ~90 atomics/us (2048 workgroups made this pass atomic-bound: 57 us)
-  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx.compute_units());
-  reach_stats_kernel<label_t><<<grid ? grid : 1, 256, 0, ctx.stream()>>>(d_labels, unreached, g->d_ap, n, source,
+  // two 1024-thread workgroups per CU: the three result words take one atomic each per workgroup, and
+  // a single device line retires ~90 atomics/us (2048 workgroups made this pass atomic-bound: 57 us)
+  const unsigned grid =
+      (unsigned)std::min<int64_t>((n + REACH_BLOCK - 1) / REACH_BLOCK, 2 * (int64_t)ctx.compute_units());
+  reach_stats_kernel<label_t><<<grid ? grid : 1, REACH_BLOCK, 0, ctx.stream()>>>(d_labels, unreached, g->d_ap, n, source,
                                                                  ctx.workspace().counters());
   GRX_HIP_CHECK(hipGetLastError());
   unsigned long long* m = operators::advance::detail::fetch_counters(ctx);

@@ -880,6 +880,9 @@ __global__ void __launch_bounds__(SET_BLOCK)
       const pending_t e = w_pending[n_pending + lane];
       nbr = e.neighbor;
       keep = op(e.source, e.neighbor, e.edge, G.get_edge_weight(e.edge));
+#if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 3  // timing experiment: functor without the output path
+      keep = keep && nbr < 0;
+#endif
     }
     if constexpr (HAS_OUT)
       wq.push_deferred(keep, nbr, output, capacity, counters, degree_of);
