@@ -33,7 +33,8 @@ def one(pattern):
 
 
 ADVANCE = ("block_mapped_kernel", "chunk_kernel", "classify_hubs_kernel", "expand_fused_kernel",
-           "wave_chunk_kernel", "pull_probe_kernel", "pull_long_kernel")
+           "expand_settled_kernel", "rebuild_kernel", "wave_chunk_kernel", "pull_probe_kernel",
+           "pull_long_kernel")
 
 
 def attribute(name):
@@ -55,15 +56,28 @@ def attribute(name):
 
 
 def attribute_all(names):
-    """attribute() over dispatches in launch order; a hub pre-pass (no functor in its template
-    arguments) belongs to the client of the expansion kernel launched right after it."""
+    """attribute() over dispatches in launch order.  A hub pre-pass (no functor in its template
+    arguments) belongs to the client of the expansion kernel launched right after it.  A push BFS run
+    (its dispatches end with reach_stats_kernel) that has a wide level but no expand_settled_kernel is
+    the call_every_edge formulation of bench.py's roofline leg: client "bfs_every_edge"."""
     out = [attribute(n) for n in names]
     for i, (k, c) in enumerate(out):
         if k == "classify_hubs_kernel" and c == "-":
             for k2, c2 in out[i + 1:i + 3]:
-                if k2 == "expand_fused_kernel":
+                if k2 in ("expand_fused_kernel", "expand_settled_kernel"):
                     out[i] = (k, c2)
                     break
+    start = 0
+    for i, (k, c) in enumerate(out + [("reach_stats_kernel", "-")]):
+        if k != "reach_stats_kernel":
+            continue
+        run = range(start, min(i, len(out)))
+        mine = [out[j][0] for j in run if out[j][1] == "bfs"]
+        if "expand_fused_kernel" in mine and "expand_settled_kernel" not in mine:
+            for j in run:
+                if out[j][1] == "bfs":
+                    out[j] = (out[j][0], "bfs_every_edge")
+        start = i + 1
     return out
 
 
@@ -88,7 +102,7 @@ with open(PRE + "kernel_trace_advance.csv", "w", newline="") as f:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         per_kernel[(k, c)][0] += 1
         per_kernel[(k, c)][1] += (e - s) / 1e3
-        if c in ("bfs", "sssp") and k in ADVANCE:
+        if c in ("bfs", "bfs_every_edge", "sssp") and k in ADVANCE:
             per_client_us[c] += (e - s) / 1e3
         if c in ("pagerank_push", "pagerank_pull"):
             per_client_us[c] += (e - s) / 1e3
@@ -108,12 +122,17 @@ runs = stats_bench.get("runs_in_process", {})
 pr = stats_bench.get("pagerank", {})
 trace = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
          "bfs_advance_us_per_traversal": per_client_us["bfs"] / runs["bfs"] if runs.get("bfs") else None,
-         "sssp_advance_us_per_traversal": per_client_us["sssp"] / runs["sssp"] if runs.get("sssp") else None,
+         "bfs_every_edge_advance_us_per_traversal":
+             per_client_us["bfs_every_edge"] / runs["bfs_call_every_edge"] if runs.get("bfs_call_every_edge") else None,
+         "sssp_advance_us_per_traversal":
+             per_client_us["sssp"] / (runs["sssp"] + runs.get("sssp_two_pass", 0)) if runs.get("sssp") else None,
          "pagerank_push_us_per_iteration":
              per_client_us["pagerank_push"] / pr["push"]["iterations"] if pr.get("push") else None,
          "pagerank_pull_us_per_iteration":
              per_client_us["pagerank_pull"] / pr["pull"]["iterations"] if pr.get("pull") else None,
          "bench_live": {"bfs_kernel_ms": stats_bench.get("roofline", {}).get("kernel_ms"),
+                        "bfs_every_edge_kernel_ms": stats_bench.get("roofline", {}).get(
+                            "call_every_edge_formulation", {}).get("kernel_ms"),
                         "sssp_kernel_ms": stats_bench.get("roofline_sssp", {}).get("kernel_ms"),
                         "pagerank_push_ms_per_iteration": pr.get("push", {}).get("ms_per_iteration"),
                         "pagerank_pull_ms_per_iteration": pr.get("pull", {}).get("ms_per_iteration")},
@@ -175,6 +194,7 @@ def traffic(client, per, kernels=None, unit="traversal"):
 
 
 tr = {"bfs": traffic("bfs", pmc_runs.get("bfs"), ADVANCE),
+      "bfs_every_edge": traffic("bfs_every_edge", pmc_runs.get("bfs_call_every_edge"), ADVANCE),
       "sssp": traffic("sssp", (pmc_runs.get("sssp", 0) + pmc_runs.get("sssp_two_pass", 0)) or None, ADVANCE),
       "pagerank_push": traffic("pagerank_push", pmc_pr.get("push", {}).get("iterations"), None, "iteration"),
       "pagerank_pull": traffic("pagerank_pull", pmc_pr.get("pull", {}).get("iterations"), None, "iteration")}
@@ -201,7 +221,7 @@ with open(PRE + "pmc_l2.csv", "w", newline="") as f:
     w.writerow(["pass", "dispatch", "kernel", "client", "counter", "value"])
     for name, table in (("l2busy", busy_disp), ("l2hit", hit_disp)):
         for did, d in table.items():
-            if d["client"] in ("bfs", "sssp", "pagerank_push", "pagerank_pull", "probe"):
+            if d["client"] in ("bfs", "bfs_every_edge", "sssp", "pagerank_push", "pagerank_pull", "probe"):
                 for cn, cv in d["counters"].items():
                     w.writerow([name, did, d["kernel"], d["client"], cn, f"{cv:.0f}"])
 
@@ -239,7 +259,8 @@ latest = {
                     "pagerank_bytes_per_iteration": pmc_pr.get("algorithmic_bytes_per_iteration")},
     "trace": trace,
     "l2": {"busy_frac_bfs_advance": l2("bfs")["busy_frac"], "hit_rate_bfs_advance": l2("bfs")["hit_rate"],
-           "by_client": {c: l2(c) for c in ("bfs", "sssp", "pagerank_push", "pagerank_pull", "probe")},
+           "by_client": {c: l2(c) for c in ("bfs", "bfs_every_edge", "sssp", "pagerank_push", "pagerank_pull",
+                                            "probe")},
            "reading": "TCC_BUSY/TCC_CYCLE summed over the 128 L2 channels and all dispatches of the client"},
 }
 json.dump(latest, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
