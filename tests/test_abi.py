@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(tmp_path):
     """Every struct that crosses the C ABI: size and the offset of every field as a C compiler
     lays the header out (gcc on include/essentials_amd.h) against the ctypes mirror in api.py."""
     from essentials_amd.api import _Options, _PartitionedStats, _Stats
-    assert C.sizeof(_Options) == 12 * 4         # 12 x int32/float
+    assert C.sizeof(_Options) == 13 * 4         # 13 x int32/float
     assert C.sizeof(_Stats) == 4 * 4 + 2 * 8 + 2 * 4 + 64 * 8 + 8
     mirrors = {"grx_options": _Options, "grx_stats": _Stats, "grx_partitioned_stats": _PartitionedStats}
     lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{HEADER}"', "int main(void) {"]
