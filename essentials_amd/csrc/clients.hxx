@@ -368,6 +368,11 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
         return false;
       return math::atomic::exch(&stamp[dst], round) != round;
     };
+    // Measured and not used here: the per-edge form of the settled hint (operators/settled.hxx,
+    // with_rejects: the engine evaluates `!(distance[src] + w < distance[dst])` for every edge with
+    // the loads batched and calls relax() on packed groups of the edges that pass).  RMAT-22, source
+    // 0: iterations 1 / 2 / 3 take 1387 / 928 / 290 us against 1310 / 968 / 288 us -- 10 % of the edges
+    // survive, and their relax() calls cost what the batching saves.
     operators::advance::execute<lb>(G, E, relax, context);
   }
 };

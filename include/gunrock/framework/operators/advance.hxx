@@ -330,8 +330,9 @@ void execute(graph_t& G,
   const std::size_t fused_from = context.options().fused_min_slots;
   bool use_settled = false;
   if constexpr (settled_traits<operator_t>::value)
-    use_settled = op.settled.bits && op.settled.limit > 0 && context.options().settled_filter &&
-                  work_bound != ~0ull && work_bound >= context.options().settled_min_work;
+    use_settled = ((op.settled.bits && op.settled.limit > 0) || operator_t::has_predicate) &&
+                  context.options().settled_filter && work_bound != ~0ull &&
+                  work_bound >= context.options().settled_min_work;
   if (!holes && !dynamic_tiles && ((fused_from && n_in >= fused_from) || use_settled)) {
     // scratch: [8 claim cursors, one 128-B line each | hub mask, one bit per input slot]
     auto* cursors = reinterpret_cast<unsigned long long*>(context.workspace().scratch(
@@ -347,7 +348,9 @@ void execute(graph_t& G,
       // in its LDS (advance_kernels.hxx: expand_settled_kernel)
       if (use_settled) {
         auto kernel = k::expand_settled_kernel<input_type, output_type, graph_t, operator_t, vertex_t, edge_t>;
-        const std::size_t lds = (std::size_t)op.settled.limit / 8;
+        if (!op.settled.bits)  // a predicate only: no bitmap to keep in LDS
+          op.settled.limit = 0;
+        const std::size_t lds = op.settled.limit > 0 ? (std::size_t)op.settled.limit / 8 : 16;
         static std::atomic<std::size_t> allowed{0};  // per instantiation: the opt-in is sticky
         if (allowed.load(std::memory_order_relaxed) < lds) {
           GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

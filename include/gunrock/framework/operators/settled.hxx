@@ -8,9 +8,10 @@
  * and to change nothing (BFS: v already has a depth).  The client names settled destinations in
  * two forms, either of which may be stale or partial -- "not settled" promises nothing:
  *   - a bitmap, one bit per vertex id below `limit` (settled_filter_t), and / or
- *   - a PURE device predicate `settled(v)` (plain loads, no side effects),
- * and the engine is then free -- not obliged -- to skip the functor call for an edge whose
- * destination is settled.
+ *   - a PURE device predicate (plain loads, no side effects), either of the destination alone,
+ *     `settled(v)`, or of the whole edge, `rejects(src, dst, edge, weight)` -- "the functor would
+ *     return false for THIS edge and change nothing" (SSSP: dist[dst] <= dist[src] + w),
+ * and the engine is then free -- not obliged -- to skip the functor call for such an edge.
  *
  * Why.  A wide level is bound by what happens per edge inside the opaque functor: a label lookup
  * (one L2 request per edge) and, where it passes, a memory-side atomic whose round trip every lane
@@ -26,6 +27,7 @@
  *   settled.rebuild(n_vertices, has_depth, ctx);
  *   operators::advance::execute<lb>(
  *       G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+ *   // SSSP, per edge:  with_rejects<vertex_t>(relax, [dist] __device__(src, dst, e, w) { return !(dist[src] + w < dist[dst]); })
  *
  * Schedules other than block_mapped's wide-level form call the functor for every edge as before.
  */
@@ -59,28 +61,46 @@ struct settled_never_t {
 };
 
 /// A functor with a settled view and predicate attached.  Callable like the functor itself.
-template <typename op_t, typename pred_t, typename vertex_t>
+/// per_edge: the predicate takes (src, dst, edge, weight) instead of (dst).
+template <typename op_t, typename pred_t, typename vertex_t, bool per_edge = false>
 struct settled_op_t {
+  static constexpr bool has_predicate = !std::is_same<pred_t, settled_never_t>::value;
   op_t op;
   settled_view_t<vertex_t> settled;
   pred_t is_settled;
+  /// The predicate in whichever form the client wrote it.
+  template <typename edge_t, typename weight_t>
+  __device__ __forceinline__ bool rejects(vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                          weight_t const& weight) const {
+    if constexpr (per_edge)
+      return is_settled(src, dst, edge, weight);
+    else
+      return is_settled(dst);
+  }
   template <typename... args_t>
   __host__ __device__ __forceinline__ bool operator()(args_t const&... args) const {
     return op(args...);
   }
 };
 
+/// Settled DESTINATIONS: a bitmap and / or a pure predicate of the destination vertex.
 template <typename op_t, typename vertex_t, typename pred_t = settled_never_t>
-settled_op_t<op_t, pred_t, vertex_t> with_settled(op_t op,
-                                                  settled_view_t<vertex_t> view,
-                                                  pred_t pred = pred_t()) {
-  return settled_op_t<op_t, pred_t, vertex_t>{op, view, pred};
+settled_op_t<op_t, pred_t, vertex_t, false> with_settled(op_t op,
+                                                         settled_view_t<vertex_t> view,
+                                                         pred_t pred = pred_t()) {
+  return settled_op_t<op_t, pred_t, vertex_t, false>{op, view, pred};
+}
+
+/// Rejected EDGES: a pure predicate of (src, dst, edge, weight).
+template <typename vertex_t, typename op_t, typename pred_t>
+settled_op_t<op_t, pred_t, vertex_t, true> with_rejects(op_t op, pred_t pred) {
+  return settled_op_t<op_t, pred_t, vertex_t, true>{op, settled_view_t<vertex_t>{}, pred};
 }
 
 template <typename T>
 struct settled_traits : std::false_type {};
-template <typename op_t, typename pred_t, typename vertex_t>
-struct settled_traits<settled_op_t<op_t, pred_t, vertex_t>> : std::true_type {};
+template <typename op_t, typename pred_t, typename vertex_t, bool per_edge>
+struct settled_traits<settled_op_t<op_t, pred_t, vertex_t, per_edge>> : std::true_type {};
 
 namespace detail_settled {
 /// One wavefront per 64 ids: the ballot of the predicate IS the two bitmap words.

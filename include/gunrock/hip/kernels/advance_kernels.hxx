@@ -828,6 +828,7 @@ __global__ void __launch_bounds__(SET_BLOCK)
                           const unsigned long long* __restrict__ hub_mask,
                           unsigned long long* __restrict__ claim_cursors) {
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
+  using weight_t = typename graph_t::weight_type;
   using pending_t = pending_edge_t<vertex_t, edge_t>;
   extern __shared__ unsigned s_settled[];  // op.settled.limit bits
   __shared__ vertex_t s_vertex[SET_BLOCK];
@@ -890,8 +891,8 @@ __global__ void __launch_bounds__(SET_BLOCK)
   // one round = four edges per lane: bitmap, predicate (independent loads), pack, call on full
   // groups
   auto consider = [&](const vertex_t (&src)[SET_UNROLL], const vertex_t (&nbr)[SET_UNROLL],
-                      const edge_t (&eid)[SET_UNROLL], const bool (&live)[SET_UNROLL])
-      __attribute__((always_inline)) {
+                      const edge_t (&eid)[SET_UNROLL], const weight_t (&wgt)[SET_UNROLL],
+                      const bool (&live)[SET_UNROLL]) __attribute__((always_inline)) {
     bool open[SET_UNROLL];
 #pragma unroll
     for (int k = 0; k < SET_UNROLL; ++k)
@@ -907,7 +908,7 @@ __global__ void __launch_bounds__(SET_BLOCK)
 #if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 1  // timing experiment: columns + LDS only
       done[k] = true;
 #else
-      done[k] = (bool)op.is_settled(open[k] ? nbr[k] : vertex_t(0));
+      done[k] = (bool)op.rejects(src[k], open[k] ? nbr[k] : vertex_t(0), eid[k], wgt[k]);
 #endif
     __builtin_amdgcn_sched_barrier(0);  // all the loads first, then their consumers
 #pragma unroll
@@ -942,18 +943,20 @@ __global__ void __launch_bounds__(SET_BLOCK)
   // round r is considered, so they fly together with r's predicate loads.
   vertex_t p_src[SET_UNROLL], p_nbr[SET_UNROLL];
   edge_t p_eid[SET_UNROLL];
+  weight_t p_wgt[SET_UNROLL];  // dead (and gone) when the predicate looks at the destination only
   bool p_live[SET_UNROLL];
   bool have_prev = false;  // wave-uniform
   auto submit = [&](const vertex_t (&src)[SET_UNROLL], const vertex_t (&nbr)[SET_UNROLL],
-                    const edge_t (&eid)[SET_UNROLL], const bool (&live)[SET_UNROLL])
-      __attribute__((always_inline)) {
+                    const edge_t (&eid)[SET_UNROLL], const weight_t (&wgt)[SET_UNROLL],
+                    const bool (&live)[SET_UNROLL]) __attribute__((always_inline)) {
     if (have_prev)
-      consider(p_src, p_nbr, p_eid, p_live);
+      consider(p_src, p_nbr, p_eid, p_wgt, p_live);
 #pragma unroll
     for (int k = 0; k < SET_UNROLL; ++k) {
       p_src[k] = src[k];
       p_nbr[k] = nbr[k];
       p_eid[k] = eid[k];
+      p_wgt[k] = wgt[k];
       p_live[k] = live[k];
     }
     have_prev = true;
@@ -992,6 +995,7 @@ __global__ void __launch_bounds__(SET_BLOCK)
     for (unsigned i0 = 0; i0 < total; i0 += wave_size * SET_UNROLL) {
       vertex_t src[SET_UNROLL], nbr[SET_UNROLL];
       edge_t eid[SET_UNROLL];
+      weight_t wgt[SET_UNROLL];
       bool live[SET_UNROLL];
 #pragma unroll
       for (int k = 0; k < SET_UNROLL; ++k) {
@@ -999,14 +1003,16 @@ __global__ void __launch_bounds__(SET_BLOCK)
         live[k] = i < total;
         src[k] = nbr[k] = 0;
         eid[k] = 0;
+        wgt[k] = weight_t(0);
         if (live[k]) {
           const int slot = rightmost_le(w_scan, i, wave_size);
           src[k] = w_vertex[slot];
           eid[k] = w_first[slot] + (edge_t)(i - w_scan[slot]);
           nbr[k] = G.get_destination_vertex(eid[k]);
+          wgt[k] = G.get_edge_weight(eid[k]);
         }
       }
-      submit(src, nbr, eid, live);
+      submit(src, nbr, eid, wgt, live);
     }
     __builtin_amdgcn_wave_barrier();  // the tile arrays are rewritten; rounds carry their sources
     tile += wave_stride;
@@ -1049,22 +1055,24 @@ __global__ void __launch_bounds__(SET_BLOCK)
         for (int j0 = 0; j0 < d.count; j0 += wave_size * SET_UNROLL) {
           vertex_t src[SET_UNROLL], nbr[SET_UNROLL];
           edge_t eid[SET_UNROLL];
+          weight_t wgt[SET_UNROLL];
           bool live[SET_UNROLL];
 #pragma unroll
           for (int k = 0; k < SET_UNROLL; ++k) {
             const int j = j0 + k * wave_size + lane;
             live[k] = j < d.count;
             src[k] = d.source;
-            eid[k] = d.first + (edge_t)j;
+            eid[k] = live[k] ? d.first + (edge_t)j : edge_t(0);
             nbr[k] = live[k] ? G.get_destination_vertex(eid[k]) : vertex_t(0);
+            wgt[k] = live[k] ? G.get_edge_weight(eid[k]) : weight_t(0);
           }
-          submit(src, nbr, eid, live);
+          submit(src, nbr, eid, wgt, live);
         }
       }
     }
   }
   if (have_prev)
-    consider(p_src, p_nbr, p_eid, p_live);
+    consider(p_src, p_nbr, p_eid, p_wgt, p_live);
 #ifdef GRX_SETTLED_STATS
   if (lane == 0) {  // diagnostic build: functor calls, edges they carried, predicate tests, rounds
     atomicAdd(&counters[10], st_calls);

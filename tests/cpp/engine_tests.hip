@@ -303,6 +303,35 @@ int main(int argc, char** argv) {
     ok = true;
     for (int v = 0; v < hg.n; ++v) ok &= is_named(v) ? hh[v] == 0 : hh[v] == want_hits[v];
     if (!ok) { std::printf("FAIL settled hint (vertices->none)\n"); ++failures; }
+    // the per-edge form: a pure predicate of (src, dst, edge, weight), no bitmap
+    {
+      auto by_edge = [] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                            weight_t const& w) -> bool { return (s + 2 * d + e) % 3 == 0; };
+      auto edge_hinted = operators::advance::with_rejects<vertex_t>(op, by_edge);
+      std::vector<long long> want_calls(hg.n, 0);
+      std::multiset<int> want_kept;
+      for (int v : fin_h) {
+        if (v < 0) continue;
+        for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) {
+#ifndef GRX_ADVANCE_LB_OVERRIDE
+          if ((v + 2 * hg.aj[e] + e) % 3 == 0) continue;
+#endif
+          want_calls[hg.aj[e]] += 1;
+          if ((v + hg.aj[e]) % 2 == 0) want_kept.insert(hg.aj[e]);
+        }
+      }
+      hits.zero();
+      operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(G, edge_hinted, &fin, &fout, segments, *mc);
+      auto o2 = fout.to_host();
+      std::multiset<int> got2(o2.begin(), o2.end());
+      got2.erase(-1);
+      hh = hits.to_host();
+      ok = true;
+      for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_calls[v];
+      if (!(ok && got2 == want_kept)) { std::printf("FAIL rejected-edge hint (vertices->vertices)\n"); ++failures; }
+    }
     // switched off, or on a schedule without the LDS filter, the functor sees every edge
     ctx0->options().settled_filter = false;
     hits.zero();
