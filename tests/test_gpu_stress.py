@@ -170,3 +170,38 @@ def test_random_pagerank_pull_and_push(env, oracle):
             p = host(p)
             assert np.abs(p - want).max() < 5e-6 and abs(st.iterations - it) <= 1, (trial, pull, scale, sym)
         g.close()
+
+
+def test_settled_form_on_small_and_odd_graphs(oracle, monkeypatch):
+    """The settled-destination form of the wide BFS levels (operators/settled.hxx), forced onto
+    every level of small graphs whose sizes are not multiples of the bitmap's 128-bit groups, with
+    tiny hub thresholds and a capped chunk queue; depths, counts and frontier lengths against the
+    oracle and against the functor-per-edge form.  (The thresholds are read when a context is made.)"""
+    import torch
+    import essentials_amd as ea
+    monkeypatch.setenv("GRX_SETTLED_MIN_WORK", "1")
+    monkeypatch.setenv("GRX_FUSED_MIN_SLOTS", "64")
+    ctx = ea.Context(0)
+    rng = np.random.default_rng(2024 + int(os.environ.get("GRX_STRESS_SEED", "0")))
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 500, 1000, 4097, 20011]))
+        m = int(rng.integers(0, 12 * n + 1))
+        rows = np.sort(rng.integers(0, n, m)).astype(np.int32)
+        hubs = rng.random(m) < 0.3                      # a few heavy destinations / sources
+        cols = np.where(hubs, rng.integers(0, max(1, n // 50), m), rng.integers(0, n, m)).astype(np.int32)
+        Ap = np.zeros(n + 1, np.int32)
+        np.add.at(Ap, rows + 1, 1)
+        Ap = np.cumsum(Ap).astype(np.int32)
+        Aj = np.ascontiguousarray(cols)
+        Ax = np.ones(m, np.float32)
+        G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+        deg = np.diff(Ap)
+        for s in {0, int(rng.integers(0, n)), int(np.argmax(deg))}:
+            want, _ = oracle.bfs_heap(Ap, Aj, s)
+            o = dict(hub_threshold=int(rng.choice([0, 4, 64])), chunk_edges=int(rng.choice([0, 8, 256])),
+                     chunk_queue_limit=int(rng.choice([0, 0, 3])))
+            d1, st1 = ea.bfs(ctx, G, s, options=ea.Options(**o))
+            d0, st0 = ea.bfs(ctx, G, s, options=ea.Options(call_every_edge=True, **o))
+            assert (host(d1) == want).all() and (host(d0) == want).all(), (trial, n, m, s, o)
+            assert st1.frontier_slots == st0.frontier_slots, (trial, n, m, s, o)
+            assert st1.edges_traversed == st0.edges_traversed == int(deg[want != INF_I].sum())
