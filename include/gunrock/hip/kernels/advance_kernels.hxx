@@ -880,7 +880,11 @@ __global__ void __launch_bounds__(SET_BLOCK)
     if ((unsigned)lane < count) {
       const pending_t e = w_pending[n_pending + lane];
       nbr = e.neighbor;
+#if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 5  // timing experiment: packing and calling, no functor
+      keep = e.neighbor < 0;
+#else
       keep = op(e.source, e.neighbor, e.edge, G.get_edge_weight(e.edge));
+#endif
 #if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 3  // timing experiment: functor without the output path
       keep = keep && nbr < 0;
 #endif
