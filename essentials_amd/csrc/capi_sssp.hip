@@ -22,6 +22,7 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, source, d_distances, ctx->mc);
+      problem.packed_labels = o.sssp_two_pass == 0;  // the reference's formulation keeps its two arrays
       problem.init();
       problem.reset();
       enactor_properties_t props;

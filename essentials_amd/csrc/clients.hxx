@@ -276,28 +276,73 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   vertex_t source;
   weight_t* distance;  // device, |V|, caller-owned
   hip::device_array_t<int> stamp;  // iteration in which a vertex last entered the frontier
+  // One-pass form: (order-preserving bits of the distance) << 32 | round + 1 of the last improvement,
+  // so that ONE 64-bit atomic min both lowers the distance and tells the first improver of a round
+  // (the two-word form needs an atomic min and an atomic exchange per improvement, i.e. two scattered
+  // memory-side RMWs -- the rate SSSP runs at).  Unpacked into `distance` when the run ends.
+  bool packed_labels = true;
+  hip::device_array_t<unsigned long long> packed;
   level_log_t log;
+
+  /// float <-> 32 bits whose UNSIGNED order is the float order (negative values included).
+  __host__ __device__ static unsigned ordered_bits(weight_t x) {
+    static_assert(sizeof(weight_t) == 4, "the packed SSSP labels hold a 32-bit distance");
+    unsigned b;
+    memcpy(&b, &x, 4);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+  }
+  __host__ __device__ static weight_t from_ordered_bits(unsigned u) {
+    const unsigned b = u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu);
+    weight_t x;
+    memcpy(&x, &b, 4);
+    return x;
+  }
 
   sssp_problem_t(graph_t& G, vertex_t _source, weight_t* _distance,
                  std::shared_ptr<gcuda::multi_context_t> ctx)
       : gunrock::problem_t<graph_t>(G, ctx), source(_source), distance(_distance) {}
 
   void init() override {
-    stamp.resize((std::size_t)this->get_graph().get_number_of_vertices());
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    if (packed_labels)
+      packed.resize(n);
+    else
+      stamp.resize(n);
   }
   void reset() override {
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
-    weight_t* d = distance;
-    int* st = stamp.data();
     const vertex_t s = source;
-    hip::for_each_index(
-        n, [d, st, s] __device__(std::size_t i) {
-          d[i] = (vertex_t)i == s ? weight_t(0) : std::numeric_limits<weight_t>::max();
-          st[i] = -1;
-        },
-        ctx->stream());
+    if (packed_labels) {
+      unsigned long long* p = packed.data();
+      const unsigned long long zero = (unsigned long long)ordered_bits(weight_t(0)) << 32;
+      const unsigned long long far = (unsigned long long)ordered_bits(std::numeric_limits<weight_t>::max()) << 32;
+      hip::for_each_index(
+          n, [p, s, zero, far] __device__(std::size_t i) { p[i] = (vertex_t)i == s ? zero : far; },
+          ctx->stream());
+    } else {
+      weight_t* d = distance;
+      int* st = stamp.data();
+      hip::for_each_index(
+          n, [d, st, s] __device__(std::size_t i) {
+            d[i] = (vertex_t)i == s ? weight_t(0) : std::numeric_limits<weight_t>::max();
+            st[i] = -1;
+          },
+          ctx->stream());
+    }
     log = level_log_t();
+  }
+  /// Packed form: write the caller's distance array (one pass, on the context's stream).
+  void unpack() {
+    if (!packed_labels)
+      return;
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    const unsigned long long* p = packed.data();
+    weight_t* d = distance;
+    hip::for_each_index(
+        n, [p, d] __device__(std::size_t i) { d[i] = from_ordered_bits((unsigned)(p[i] >> 32)); },
+        ctx->stream());
   }
 };
 
@@ -324,6 +369,8 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
       return true;
     return base_t::is_converged(context);
   }
+
+  void finalize(gcuda::multi_context_t&) override { this->get_problem()->unpack(); }
 
   void loop(gcuda::multi_context_t& context) override {
     auto E = this->get_enactor();
@@ -358,6 +405,25 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
       };
       operators::advance::execute<lb>(G, E, relax_all, context);
       operators::filter::execute<operators::filter_algorithm_t::bypass>(G, E, once, context);
+      return;
+    }
+    if (P->packed_labels) {
+      unsigned long long* packed = P->packed.data();
+      const unsigned this_round = (unsigned)round + 1u;  // 0 = never improved
+      auto relax_packed = [packed, this_round] __host__ __device__(
+                              vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                              weight_t const& w) -> bool {
+        const weight_t through =
+            problem_type::from_ordered_bits((unsigned)(thread::load(&packed[src]) >> 32)) + w;
+        const unsigned long long key =
+            ((unsigned long long)problem_type::ordered_bits(through) << 32) | this_round;
+        const unsigned long long old = math::atomic::min(&packed[dst], key);
+        if (!((unsigned)(key >> 32) < (unsigned)(old >> 32)))
+          return false;                        // no shorter: (an equal distance never lowers the word,
+                                               // rounds only grow)
+        return (unsigned)old != this_round;    // the first improver of this round enqueues the vertex
+      };
+      operators::advance::execute<lb>(G, E, relax_packed, context);
       return;
     }
     auto relax = [distance, stamp, round] __host__ __device__(

@@ -106,9 +106,10 @@ typedef struct grx_options {
   int32_t chunk_queue_limit;    /* test hook, 0: none. Caps the hub chunk queue to force the overflow
                                    path (hubs expanded in place)                                    */
   int32_t sssp_two_pass;        /* grx_sssp: 0 one pass -- the relax functor keeps exactly one copy of an
-                                   improved vertex per round (atomic::exch on a stamp); 1 the reference
-                                   client's formulation, advance + bypass filter with its racy stamp
-                                   test (algorithms/sssp.hxx:110-144).  Same distances either way       */
+                                   improved vertex per round (one 64-bit atomic min on distance | round
+                                   while the search runs; d_distances is written when it ends); 1 the
+                                   reference client's formulation, advance + bypass filter with its racy
+                                   stamp test (algorithms/sssp.hxx:110-144).  Same distances either way */
   int32_t call_every_edge;      /* grx_bfs push: 0 the search names its settled destinations (vertices that
                                    have a depth) and the engine skips the functor call for an edge into one
                                    (gunrock/framework/operators/settled.hxx; wide block_mapped levels);
