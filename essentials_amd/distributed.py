@@ -132,8 +132,11 @@ class SingleRunner:
                 "relaxations_per_second_g": relax / (best.advance_kernel_ms * 1e-3) / 1e9,
                 "two_pass_reference_formulation": {
                     "enact_ms": two.elapsed_ms, "iterations": two.iterations,
-                    "relaxations": two.edges_expanded, "frontier_entries": sum(two.frontier_slots),
-                    "algorithmic_bytes": 12 * two.edges_expanded + 28 * sum(two.frontier_slots),
+                    "relaxations_upper_bound": two.edges_expanded,
+                    "frontier_entries": sum(two.frontier_slots),
+                    "relaxations_note": "sum of the input frontiers' work hints; the bypass filter turns "
+                                        "duplicates into holes and passes the advance's hint on, so "
+                                        "this counts the degrees of removed duplicates too",
                     "note": "advance + bypass filter with the racy stamp test, as reference "
                             "algorithms/sssp.hxx:110-144 (grx_options.sssp_two_pass); same distances"}}
 
