@@ -4,6 +4,15 @@
 
 using namespace essentials_amd;
 
+namespace essentials_amd {
+/// Largest |V| for which grx_sssp keeps packed 64-bit labels (GRX_SSSP_PACKED_MAX_VERTICES overrides).
+inline long long packed_sssp_max_vertices() {
+  if (const char* e = std::getenv("GRX_SSSP_PACKED_MAX_VERTICES"))
+    return std::atoll(e);
+  return 1ll << 22;  // 32 MB of labels: what the eight 4 MB L2s hold between them
+}
+}  // namespace essentials_amd
+
 extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float* d_distances,
                         int32_t* /*d_predecessors*/, const grx_options* opt, grx_stats* stats) {
   if (!ctx || !g || !d_distances)
@@ -22,7 +31,16 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, source, d_distances, ctx->mc);
-      problem.packed_labels = o.sssp_two_pass == 0;  // the reference's formulation keeps its two arrays
+      // one 64-bit label per vertex (one RMW per improvement) while 8 bytes per vertex stay
+      // cache-sized; beyond that the doubled label footprint costs more lookups that miss than the
+      // saved RMWs are worth.  Measured crossover on R-MAT (tools/sssp_packed_vs_words.py, mean
+      // enact of 3 sources, packed / two words): scale 20 1.25 / 1.42 ms, 22 2.92 / 3.11, 23 5.56 /
+      // 5.46, 24 12.8 / 11.0, 26 58.2 / 53.5.  GRX_SSSP_PACKED=0/1 overrides; the reference's
+      // two-pass formulation keeps its two arrays.
+      bool packed = g->n_rows <= essentials_amd::packed_sssp_max_vertices();
+      if (const char* e = std::getenv("GRX_SSSP_PACKED"))
+        packed = std::atoi(e) != 0;
+      problem.packed_labels = packed && o.sssp_two_pass == 0;
       problem.init();
       problem.reset();
       enactor_properties_t props;
