@@ -24,6 +24,13 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
       scoped_options scope(ctx->single(), &o);
       graph_type G = g->view();
       problem_type problem(G, source, d_distances, ctx->mc);
+      // push search: one byte per vertex while it runs once 4-byte depths outgrow the eight L2s
+      // (GRX_BFS_BYTE_LABELS=0/1 overrides; measurements in DESIGN.md, "Larger graphs")
+      if (!o.direction_optimized) {
+        problem.byte_labels = g->n_rows > (1ll << 22);
+        if (const char* e = std::getenv("GRX_BFS_BYTE_LABELS"))
+          problem.byte_labels = std::atoi(e) != 0;
+      }
       problem.init();
       problem.reset();
       enactor_properties_t props;

@@ -55,24 +55,58 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
   vertex_t source;
   vertex_t* depth;  // device, |V|, caller-owned
   level_log_t log;
+  // Push search on graphs whose 4-byte depths outgrow the caches: ONE BYTE per vertex while the
+  // search runs (0xFF = unvisited), four to a word; a vertex is claimed by clearing bits of its
+  // byte (atomic AND -- one RMW per discovery, like the atomic min on a word), the caller's array is
+  // written when the run ends or when level 254 is reached (the search then goes on in it).
+  bool byte_labels = false;
+  hip::device_array_t<unsigned> bytes;
 
   bfs_problem_t(graph_t& G, vertex_t _source, vertex_t* _depth,
                 std::shared_ptr<gcuda::multi_context_t> ctx)
       : gunrock::problem_t<graph_t>(G, ctx), source(_source), depth(_depth) {}
 
-  void init() override {}
+  void init() override {
+    if (byte_labels)
+      bytes.resize(((std::size_t)this->get_graph().get_number_of_vertices() + 3) / 4);
+  }
   void reset() override {
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
     // one pass, enqueued on the context's stream ahead of the traversal: nothing to wait for
-    vertex_t* d = depth;
     const vertex_t s = source;
+    if (byte_labels) {
+      unsigned* w = bytes.data();
+      hip::for_each_index(
+          (n + 3) / 4, [w, s] __device__(std::size_t i) {
+            w[i] = (std::size_t)(s >> 2) == i ? ~(0xFFu << ((s & 3) * 8)) : 0xFFFFFFFFu;
+          },
+          ctx->stream());
+    } else {
+      vertex_t* d = depth;
+      hip::for_each_index(
+          n, [d, s] __device__(std::size_t i) {
+            d[i] = (vertex_t)i == s ? vertex_t(0) : std::numeric_limits<vertex_t>::max();
+          },
+          ctx->stream());
+    }
+    log = level_log_t();
+  }
+  /// Byte form: write the caller's depth array (one pass) and continue / end in it.
+  void unpack() {
+    if (!byte_labels)
+      return;
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    const unsigned* w = bytes.data();
+    vertex_t* d = depth;
     hip::for_each_index(
-        n, [d, s] __device__(std::size_t i) {
-          d[i] = (vertex_t)i == s ? vertex_t(0) : std::numeric_limits<vertex_t>::max();
+        n, [w, d] __device__(std::size_t i) {
+          const unsigned b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+          d[i] = b == 0xFFu ? std::numeric_limits<vertex_t>::max() : (vertex_t)b;
         },
         ctx->stream());
-    log = level_log_t();
+    byte_labels = false;
   }
 };
 
@@ -99,23 +133,13 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     return base_t::is_converged(context);
   }
 
-  void loop(gcuda::multi_context_t& context) override {
-    auto E = this->get_enactor();
-    auto P = this->get_problem();
-    auto G = P->get_graph();
-    P->log.note(E->get_input_frontier()->get_number_of_elements(),
-                E->get_input_frontier()->work_hint());
+  void finalize(gcuda::multi_context_t&) override { this->get_problem()->unpack(); }
 
-    vertex_t* depth = P->depth;
-    const vertex_t next_level = this->iteration + 1;
-    auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
-                                                         edge_t const& edge,
-                                                         weight_t const& weight) -> bool {
-      // first arrival wins; later arrivals of the same level see an equal depth.  (Measured
-      // neutral in front of this test: a dense "seen" bitmap, and a batched read-only pre-test of
-      // a lane's four in-flight edges -- DESIGN.md section 5.)
-      return next_level < math::atomic::min(&depth[dst], next_level);
-    };
+  /// One level.  `visit` discovers, `has_depth` is its pure "already discovered" test.
+  template <typename visit_t, typename has_depth_t>
+  void expand(visit_t visit, has_depth_t has_depth, gcuda::multi_context_t& context) {
+    auto E = this->get_enactor();
+    auto G = this->get_problem()->get_graph();
     // wide levels (block_mapped's fused form): every vertex that has a depth is settled -- visit()
     // returns false for it and changes nothing -- so the engine may answer those lookups from LDS
     // (operators/settled.hxx).  The bitmap is rebuilt from the depths, one small kernel per level.
@@ -124,9 +148,6 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     if (lb == load_balance_t::block_mapped && ctx->options().settled_filter &&
         !ctx->options().holes_layout && work != frontier_t::unknown_work &&
         work >= ctx->options().settled_min_work) {
-      auto has_depth = [depth] __device__(vertex_t const& v) -> bool {
-        return depth[v] != std::numeric_limits<vertex_t>::max();
-      };
       {  // part of this level's advance: timed with it when kernels are timed
         operators::advance::detail::clocked_t clock(*ctx);
         settled.rebuild((std::size_t)G.get_number_of_vertices(), has_depth, *ctx);
@@ -137,6 +158,51 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     } else {
       operators::advance::execute<lb>(G, E, visit, context);
     }
+  }
+
+  void loop(gcuda::multi_context_t& context) override {
+    auto E = this->get_enactor();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
+    P->log.note(E->get_input_frontier()->get_number_of_elements(),
+                E->get_input_frontier()->work_hint());
+
+    vertex_t* depth = P->depth;
+    const vertex_t next_level = this->iteration + 1;
+    if (P->byte_labels && next_level >= 255)
+      P->unpack();  // a byte cannot hold this level: go on in the caller's array
+    if (P->byte_labels) {
+      unsigned* words = P->bytes.data();
+      const unsigned level = (unsigned)next_level;
+      auto visit_byte = [words, level] __device__(vertex_t const& src, vertex_t const& dst,
+                                                  edge_t const& edge, weight_t const& weight) -> bool {
+        unsigned* w = words + ((unsigned)dst >> 2);
+        const unsigned shift = ((unsigned)dst & 3u) * 8u;
+        // a fresh (agent-scope) look first: the RMW executes at the memory side
+        if (((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> shift) & 0xFFu) != 0xFFu)
+          return false;
+        // 0xFF & level = level; a concurrent claim of the same level leaves the same byte
+        const unsigned old = ::atomicAnd(w, ~(0xFFu << shift) | (level << shift));
+        return ((old >> shift) & 0xFFu) == 0xFFu;
+      };
+      auto has_byte = [words] __device__(vertex_t const& v) -> bool {
+        return ((words[(unsigned)v >> 2] >> (((unsigned)v & 3u) * 8u)) & 0xFFu) != 0xFFu;
+      };
+      expand(visit_byte, has_byte, context);
+      return;
+    }
+    auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                         edge_t const& edge,
+                                                         weight_t const& weight) -> bool {
+      // first arrival wins; later arrivals of the same level see an equal depth.  (Measured
+      // neutral in front of this test: a dense "seen" bitmap, and a batched read-only pre-test of
+      // a lane's four in-flight edges -- DESIGN.md section 5.)
+      return next_level < math::atomic::min(&depth[dst], next_level);
+    };
+    auto has_depth = [depth] __device__(vertex_t const& v) -> bool {
+      return depth[v] != std::numeric_limits<vertex_t>::max();
+    };
+    expand(visit, has_depth, context);
   }
   operators::advance::settled_filter_t<vertex_t> settled;
 };

@@ -345,6 +345,42 @@ def test_bfs_settled_hint_changes_nothing(ea, ctx, oracle, scale, limit):
         assert st1.vertices_reached == st0.vertices_reached == int((want != INF_I).sum())
 
 
+def test_bfs_byte_labels_change_nothing(ea, ctx, oracle, monkeypatch):
+    """Graphs beyond 2^22 vertices run the push search on one byte per vertex (clients.hxx); forced
+    here onto small graphs: same depths, counts and frontier lengths as with the caller's 4-byte
+    array, also past level 254, where the search continues in that array."""
+    graphs = []
+    g = ea.Graph.rmat(ctx, 17, 16, seed=5, weight_seed=0)
+    graphs.append((g,) + tuple(g.to_host()[:2]))
+    n = 1203                                     # a path with a few chords: 1000+ levels
+    rows = np.arange(n - 1, dtype=np.int32)
+    src = np.concatenate([rows, rows + 1, [0, 700]]).astype(np.int32)
+    dst = np.concatenate([rows + 1, rows, [5, 1100]]).astype(np.int32)
+    order = np.lexsort((dst, src))
+    Ap = np.zeros(n + 1, np.int32)
+    np.add.at(Ap, src + 1, 1)
+    Ap = np.cumsum(Ap).astype(np.int32)
+    Aj = np.ascontiguousarray(dst[order])
+    graphs.append((ea.Graph.from_host_csr(Ap, Aj, np.ones(len(Aj), np.float32)), Ap, Aj))
+    rng = np.random.default_rng(7 + SEED_OFFSET)
+    for G, Ap, Aj in graphs:
+        deg = np.diff(Ap)
+        for s in [0] + rng.choice(np.flatnonzero(deg > 0), 3).tolist():
+            want, _ = oracle.bfs_heap(Ap, np.ascontiguousarray(Aj), int(s))
+            monkeypatch.setenv("GRX_BFS_BYTE_LABELS", "1")
+            d1, st1 = ea.bfs(ctx, G, int(s))
+            d1 = host(d1).copy()
+            d2, _ = ea.bfs(ctx, G, int(s), options=ea.Options(call_every_edge=True,
+                                                             load_balance=ea.LoadBalance.merge_path))
+            d2 = host(d2).copy()
+            monkeypatch.setenv("GRX_BFS_BYTE_LABELS", "0")
+            d0, st0 = ea.bfs(ctx, G, int(s))
+            assert (d1 == want).all() and (d2 == want).all() and (host(d0) == want).all(), s
+            assert st1.frontier_slots == st0.frontier_slots and st1.iterations == st0.iterations
+            assert st1.edges_traversed == st0.edges_traversed == int(deg[want != INF_I].sum())
+        monkeypatch.delenv("GRX_BFS_BYTE_LABELS")
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json's full size (RMAT-22): size-independent properties
 # ---------------------------------------------------------------------------
