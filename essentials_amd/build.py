@@ -56,7 +56,11 @@ def build_variant(name: str, defines, only=None, jobs: int | None = None) -> str
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     todo, objs = [], []
     for s in sources:
-        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        base = os.path.basename(s)[:-4]
+        if only and base not in only:
+            objs.append(os.path.join(OBJ, base + ".o"))  # the product build's object, unchanged
+            continue
+        o = os.path.join(objdir, base + ".o")
         objs.append(o)
         todo.append((s, o))
     with ThreadPoolExecutor(jobs or 8) as ex:
@@ -124,10 +128,12 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--variant", default=None, help="experiment build name")
     ap.add_argument("-D", dest="defines", action="append", default=[])
+    ap.add_argument("--only", action="append", default=None,
+                    help="variant: recompile only these sources (basename without .hip), e.g. capi_bfs")
     a = ap.parse_args()
     try:
         if a.variant:
-            print(build_variant(a.variant, a.defines, jobs=a.jobs))
+            print(build_variant(a.variant, a.defines, only=a.only, jobs=a.jobs))
         else:
             print(build(a.force, a.jobs, verbose=True))
     except RuntimeError as e:

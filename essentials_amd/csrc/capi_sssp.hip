@@ -49,6 +49,11 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       enactor_type enactor(&problem, ctx->mc, props);
       enactor.max_iterations = o.max_iterations;
       enactor.two_pass = o.sssp_two_pass != 0;
+      enactor.bound_filter = o.call_every_edge == 0;
+      if (const char* e = std::getenv("GRX_SSSP_BOUND_FILTER"))
+        enactor.bound_filter = std::atoi(e) != 0;
+      if (const char* e = std::getenv("GRX_SSSP_BOUND_FROM"))
+        enactor.bound_from = std::atoi(e);
       const float ms = enactor.enact();
       if (stats) {
         std::memset(stats, 0, sizeof *stats);

@@ -349,6 +349,15 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   bool packed_labels = true;
   hip::device_array_t<unsigned long long> packed;
   level_log_t log;
+#ifdef GRX_SSSP_DIAG
+  hip::device_array_t<unsigned long long> diag;  // diagnostic build: 64 x {issued, won, first of round}
+#endif
+  // Wide iterations: a 2-byte UPPER BOUND of every distance as it stood when the iteration began
+  // (the top 16 of the order-preserving bits, rounded up), 8 MB at 2^22 vertices against 32 MB of
+  // packed labels: the engine's batched per-edge predicate rejects a relaxation whose candidate
+  // is not below that bound without touching the label (section 5 of DESIGN.md: the wide SSSP
+  // iterations run at the fabric's rate of 128-byte label lines).
+  hip::device_array_t<unsigned short> bound16;
 
   /// float <-> 32 bits whose UNSIGNED order is the float order (negative values included).
   __host__ __device__ static unsigned ordered_bits(weight_t x) {
@@ -374,6 +383,26 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
       packed.resize(n);
     else
       stamp.resize(n);
+#ifdef GRX_SSSP_DIAG
+    diag.resize(64 * 16);
+    diag.zero();
+#endif
+    if (packed_labels)
+      bound16.resize(n);
+  }
+  /// bound16[v] <- ceil16(ordered bits of the current distance): one pass, on the context's stream.
+  void snapshot_bounds() {
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    const unsigned long long* p = packed.data();
+    unsigned short* b = bound16.data();
+    hip::for_each_index(
+        n, [p, b] __device__(std::size_t i) {
+          const unsigned bits = (unsigned)(p[i] >> 32);
+          const unsigned up = (bits >> 16) + ((bits & 0xffffu) ? 1u : 0u);
+          b[i] = (unsigned short)(up > 0xffffu ? 0xffffu : up);
+        },
+        ctx->stream());
   }
   void reset() override {
     auto ctx = this->get_single_context();
@@ -421,6 +450,8 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
   using frontier_t = typename base_t::frontier_t;
   int max_iterations = 0;
   bool two_pass = false;  // true: advance + bypass filter, as reference algorithms/sssp.hxx does
+  bool bound_filter = true;  // wide iterations: 2-byte bound mirror in front of the labels (packed form)
+  int bound_from = -1;       // >= 0: first iteration that uses it (experiments); -1: by edges expanded so far
 
   sssp_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                  enactor_properties_t props = enactor_properties_t())
@@ -489,6 +520,87 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
                                                // rounds only grow)
         return (unsigned)old != this_round;    // the first improver of this round enqueues the vertex
       };
+#ifdef GRX_SSSP_DIAG
+      {  // diagnostic build: how many RMWs pass the pre-test, how many of them lower the label
+        unsigned long long* diag = P->diag.data();
+        auto relax_counted = [packed, this_round, diag] __device__(
+                                 vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                 weight_t const& w) -> bool {
+          const weight_t through =
+              problem_type::from_ordered_bits((unsigned)(thread::load(&packed[src]) >> 32)) + w;
+          const unsigned long long key =
+              ((unsigned long long)problem_type::ordered_bits(through) << 32) | this_round;
+          unsigned long long* slot = diag + (blockIdx.x & 63u) * 16;
+          const unsigned long long seen =
+              __hip_atomic_load(&packed[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(key < seen))
+            return false;
+          atomicAdd(slot + 0, 1ull);
+          const unsigned long long old = ::atomicMin(&packed[dst], key);
+          if (!((unsigned)(key >> 32) < (unsigned)(old >> 32)))
+            return false;
+          atomicAdd(slot + 1, 1ull);
+          if ((unsigned)old == this_round)
+            return false;
+          atomicAdd(slot + 2, 1ull);
+          return true;
+        };
+        operators::advance::execute<lb>(G, E, relax_counted, context);
+        auto h = P->diag.to_host();
+        unsigned long long t[3] = {0, 0, 0};
+        for (int b = 0; b < 64; ++b)
+          for (int k = 0; k < 3; ++k)
+            t[k] += h[b * 16 + k];
+        std::fprintf(stderr, "[sssp diag] iteration %d: RMWs issued %llu, lowered the label %llu, first of the round %llu\n",
+                     round, t[0], t[1], t[2]);
+        P->diag.zero();
+        return;
+      }
+#endif
+      {
+        auto ctx = context.get_context(0);
+        const unsigned long long work = E->get_input_frontier()->work_hint();
+        // The bounds are those of the iteration's START: while most destinations are still
+        // unreached (no bound) nearly every edge passes and the batched form only adds its packing
+        // (RMAT-22 source 0, iteration 1: 1.38 against 1.10 ms); once a quarter of the graph's edges
+        // have been expanded the hubs are reached and it pays (iterations 2 / 3: 0.98 -> 0.82, 0.30 ->
+        // 0.28 ms; with hot-first numbering 0.93 -> 0.64, 0.29 -> 0.25 ms).
+        const bool reached_enough =
+            bound_from >= 0 ? round >= bound_from
+                            : work != frontier_t::unknown_work &&
+                                  4 * ((unsigned long long)P->log.edges_expanded - work) >=  // before this one
+                                      (unsigned long long)G.get_number_of_edges();
+        if (lb == load_balance_t::block_mapped && bound_filter && reached_enough &&
+            ctx->options().settled_filter &&
+            !ctx->options().holes_layout && work != frontier_t::unknown_work &&
+            work >= ctx->options().settled_min_work) {
+          {  // part of this iteration's advance: timed with it when kernels are timed
+            operators::advance::detail::clocked_t clock(*ctx);
+            P->snapshot_bounds();
+            clock.stop();
+          }
+          const unsigned short* bound16 = P->bound16.data();
+          // PURE: "relax_packed would return false for this edge and change nothing" -- the
+          // candidate is not below an upper bound of the destination's distance (0xffff: no bound)
+          auto cached = [packed] __device__(vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                            weight_t const& w, unsigned short const& bound) -> bool {
+            const weight_t through =
+                problem_type::from_ordered_bits((unsigned)(packed[src] >> 32)) + w;
+            const unsigned b = bound;
+            return b != 0xffffu && problem_type::ordered_bits(through) >= (b << 16);
+          };
+          auto not_shorter = [cached, bound16] __device__(vertex_t const& src, vertex_t const& dst,
+                                                          edge_t const& edge, weight_t const& w) -> bool {
+            return cached(src, dst, edge, w, bound16[dst]);
+          };
+          operators::advance::execute<lb>(
+              G, E,
+              operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter, cached, bound16,
+                                                        (std::size_t)G.get_number_of_vertices()),
+              context);
+          return;
+        }
+      }
       operators::advance::execute<lb>(G, E, relax_packed, context);
       return;
     }

@@ -115,7 +115,7 @@ std::unique_ptr<grx_graph_s> rmat_build(gcuda::standard_context_t& c, unsigned s
   std::size_t bytes = 0;
   GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys.data(), keys2.data(), idx.data(),
                                           idx2.data(), slots, 0, scale + 1, s));
-  hip::buffer_t<unsigned char> temp(bytes);
+  hip::buffer_t<unsigned char> temp(bytes < 256 ? 256 : bytes);  // never null: rocPRIM would only size
   GRX_HIP_CHECK(rocprim::radix_sort_pairs(temp.data(), bytes, keys.data(), keys2.data(), idx.data(),
                                           idx2.data(), slots, 0, scale + 1, s));
   auto g = std::make_unique<grx_graph_s>();
@@ -191,7 +191,7 @@ extern "C" int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph
       std::size_t bytes = 0;
       GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys.data(), keys2.data(), g->d_ax,
                                               r->ax.data(), nnz, 0, 64, s));
-      hip::buffer_t<unsigned char> temp(bytes);
+      hip::buffer_t<unsigned char> temp(bytes < 256 ? 256 : bytes);  // never null: rocPRIM would only size
       GRX_HIP_CHECK(rocprim::radix_sort_pairs(temp.data(), bytes, keys.data(), keys2.data(), g->d_ax,
                                               r->ax.data(), nnz, 0, 64, s));
       keys_to_cols_kernel<<<grid, 256, 0, s>>>(keys2.data(), (long long)nnz, r->aj.data());

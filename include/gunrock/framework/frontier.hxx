@@ -190,7 +190,9 @@ class frontier_t {
     if (num_elements_ < 2)
       return;
     std::size_t bytes = hip::radix_sort_temp_bytes<type_t>(num_elements_);
-    hip::buffer_t<unsigned char> temp(bytes);
+    // never a null temp: rocPRIM reads "temp == nullptr" as a size query and sorts NOTHING, and the
+    // copy below would then publish the uninitialised `sorted` buffer (round-2 fault)
+    hip::buffer_t<unsigned char> temp(bytes < 256 ? 256 : bytes);
     hip::buffer_t<type_t> sorted(num_elements_);
     hip::radix_sort_keys(temp.data(), bytes, data(), sorted.data(), num_elements_, order, stream);
     GRX_HIP_CHECK(hipMemcpyAsync(data(), sorted.data(), num_elements_ * sizeof(type_t),

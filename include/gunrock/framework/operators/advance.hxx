@@ -350,7 +350,7 @@ void execute(graph_t& G,
         auto kernel = k::expand_settled_kernel<input_type, output_type, graph_t, operator_t, vertex_t, edge_t>;
         if (!op.settled.bits)  // a predicate only: no bitmap to keep in LDS
           op.settled.limit = 0;
-        const std::size_t lds = op.settled.limit > 0 ? (std::size_t)op.settled.limit / 8 : 16;
+        const std::size_t lds = op.settled.limit > 0 ? op.lds_bytes() : 16;
         static std::atomic<std::size_t> allowed{0};  // per instantiation: the opt-in is sticky
         if (allowed.load(std::memory_order_relaxed) < lds) {
           GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

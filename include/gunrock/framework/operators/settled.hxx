@@ -65,6 +65,9 @@ struct settled_never_t {
 template <typename op_t, typename pred_t, typename vertex_t, bool per_edge = false>
 struct settled_op_t {
   static constexpr bool has_predicate = !std::is_same<pred_t, settled_never_t>::value;
+  static constexpr bool per_edge_predicate = per_edge;
+  static constexpr int lds_image = 1;  ///< what the workgroup keeps in LDS: 1 = the settled bitmap
+  __host__ __device__ std::size_t lds_bytes() const { return (std::size_t)settled.limit / 8; }
   op_t op;
   settled_view_t<vertex_t> settled;
   pred_t is_settled;
@@ -97,8 +100,50 @@ settled_op_t<op_t, pred_t, vertex_t, true> with_rejects(op_t op, pred_t pred) {
   return settled_op_t<op_t, pred_t, vertex_t, true>{op, settled_view_t<vertex_t>{}, pred};
 }
 
+/// Cached BOUNDS (engine extension, per-edge form).  `values[v]`, 2 bytes per id below `limit`, is
+/// some monotone summary of the client's label of v as it stood before the advance (SSSP: an upper
+/// bound of the distance); the workgroup keeps a copy in LDS.  `cached(src, dst, edge, weight,
+/// values[dst])` is PURE and says "the functor would return false for this edge and change nothing"
+/// from that summary alone -- for ids below `limit` it is the whole test (no memory request for the
+/// destination); ids >= limit are asked through the global per-edge predicate `is_settled`.
+template <typename op_t, typename pred_t, typename cached_t, typename vertex_t>
+struct bounded_op_t {
+  static constexpr bool has_predicate = true;
+  static constexpr bool per_edge_predicate = true;
+  static constexpr int lds_image = 2;  ///< 2-byte values
+  __host__ __device__ std::size_t lds_bytes() const { return (std::size_t)settled.limit * 2; }
+  op_t op;
+  settled_view_t<vertex_t> settled;  ///< bits = the 2-byte values, limit = ids covered (multiple of 8)
+  pred_t is_settled;
+  cached_t cached;
+  template <typename edge_t, typename weight_t>
+  __device__ __forceinline__ bool rejects(vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                          weight_t const& weight) const {
+    return is_settled(src, dst, edge, weight);
+  }
+  template <typename... args_t>
+  __host__ __device__ __forceinline__ bool operator()(args_t const&... args) const {
+    return op(args...);
+  }
+};
+
+/// Ids a workgroup's LDS can hold 2-byte values for (the same 96 KB as the bitmap).
+constexpr std::size_t bounded_max_ids = (std::size_t(96) << 10) / 2;
+
+template <typename vertex_t, typename op_t, typename pred_t, typename cached_t>
+bounded_op_t<op_t, pred_t, cached_t, vertex_t> with_bounds(op_t op, pred_t pred, cached_t cached,
+                                                           const unsigned short* values,
+                                                           std::size_t n_values) {
+  std::size_t ids = n_values < bounded_max_ids ? n_values : bounded_max_ids;
+  ids = ids / 8 * 8;  // whole 16-byte groups
+  return bounded_op_t<op_t, pred_t, cached_t, vertex_t>{
+      op, settled_view_t<vertex_t>{reinterpret_cast<const unsigned*>(values), (vertex_t)ids}, pred, cached};
+}
+
 template <typename T>
 struct settled_traits : std::false_type {};
+template <typename op_t, typename pred_t, typename cached_t, typename vertex_t>
+struct settled_traits<bounded_op_t<op_t, pred_t, cached_t, vertex_t>> : std::true_type {};
 template <typename op_t, typename pred_t, typename vertex_t, bool per_edge>
 struct settled_traits<settled_op_t<op_t, pred_t, vertex_t, per_edge>> : std::true_type {};
 

@@ -98,7 +98,8 @@ auto transpose(graph_t& G, gcuda::standard_context_t& ctx) {
     GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, G.get_column_indices(), cols_sorted.data(),
                                             ids.data(), T.edge_ids.data(), nnz, 0,
                                             8 * sizeof(vertex_t), s));
-    hip::buffer_t<unsigned char> temp(bytes);
+    // never a null temp: rocPRIM reads "temp == nullptr" as a size query and sorts nothing
+    hip::buffer_t<unsigned char> temp(bytes < 256 ? 256 : bytes);
     GRX_HIP_CHECK(rocprim::radix_sort_pairs(temp.data(), bytes, G.get_column_indices(),
                                             cols_sorted.data(), ids.data(), T.edge_ids.data(), nnz, 0,
                                             8 * sizeof(vertex_t), s));

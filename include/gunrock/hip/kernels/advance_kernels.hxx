@@ -844,10 +844,10 @@ __global__ void __launch_bounds__(SET_BLOCK)
   const int lane = lane_id();
   const vertex_t limit = op.settled.limit;
   {
-    const unsigned words = (unsigned)limit / 32u;  // a multiple of 4
+    const unsigned groups = (unsigned)(op.lds_bytes() / 16u);  // the image is whole 16-byte groups
     const uint4* src = reinterpret_cast<const uint4*>(op.settled.bits);
     uint4* dst = reinterpret_cast<uint4*>(s_settled);
-    for (unsigned w = tid; w < words / 4u; w += SET_BLOCK)
+    for (unsigned w = tid; w < groups; w += SET_BLOCK)
       dst[w] = src[w];
   }
   __syncthreads();
@@ -898,9 +898,25 @@ __global__ void __launch_bounds__(SET_BLOCK)
                       const edge_t (&eid)[SET_UNROLL], const weight_t (&wgt)[SET_UNROLL],
                       const bool (&live)[SET_UNROLL]) __attribute__((always_inline)) {
     bool open[SET_UNROLL];
+    bool by_cache[SET_UNROLL];  // 2-byte image: the edge is decided from LDS alone
+    if constexpr (op_t::lds_image == 2) {
+      const unsigned short* s_values = reinterpret_cast<const unsigned short*>(s_settled);
 #pragma unroll
-    for (int k = 0; k < SET_UNROLL; ++k)
-      open[k] = !in_bitmap(nbr[k]);
+      for (int k = 0; k < SET_UNROLL; ++k) {
+        const bool covered = (unsigned)nbr[k] < (unsigned)limit;
+        const unsigned short value = s_values[covered ? (unsigned)nbr[k] : 0u];
+        // unconditional (its source-label load flies with the other lanes'); masked below
+        by_cache[k] = op.cached(src[k], nbr[k], eid[k], wgt[k], value);
+        open[k] = !covered;
+        by_cache[k] = by_cache[k] && covered;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SET_UNROLL; ++k) {
+        open[k] = !in_bitmap(nbr[k]);
+        by_cache[k] = false;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < SET_UNROLL; ++k)
       open[k] = open[k] && live[k];
@@ -916,8 +932,12 @@ __global__ void __launch_bounds__(SET_BLOCK)
 #endif
     __builtin_amdgcn_sched_barrier(0);  // all the loads first, then their consumers
 #pragma unroll
-    for (int k = 0; k < SET_UNROLL; ++k)
-      done[k] = done[k] || !open[k];
+    for (int k = 0; k < SET_UNROLL; ++k) {
+      if constexpr (op_t::lds_image == 2)  // covered: the cache's verdict; not covered: the predicate's
+        done[k] = open[k] ? done[k] : (by_cache[k] || !live[k]);
+      else
+        done[k] = done[k] || !open[k];
+    }
 #if defined(GRX_SETTLED_EXP) && GRX_SETTLED_EXP == 2  // timing experiment: lookups, no functor
 #pragma unroll
     for (int k = 0; k < SET_UNROLL; ++k)

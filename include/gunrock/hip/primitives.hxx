@@ -150,6 +150,8 @@ std::size_t radix_sort_temp_bytes(std::size_t n) {
 template <typename key_t>
 void radix_sort_keys(void* temp, std::size_t temp_bytes, const key_t* keys_in, key_t* keys_out,
                      std::size_t n, sort_order_t order, hipStream_t stream) {
+  // rocPRIM reads a null temp as "tell me the size" and sorts nothing: fail loudly instead
+  error::throw_if_exception(temp == nullptr, "radix_sort_keys: null temporary storage");
   if (order == sort_order_t::ascending)
     GRX_HIP_CHECK(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, 0,
                                            8 * sizeof(key_t), stream));
@@ -168,6 +170,7 @@ std::size_t exclusive_sum_temp_bytes(in_it in, out_it out, T init, std::size_t n
 template <typename in_it, typename out_it, typename T>
 void exclusive_sum(void* temp, std::size_t temp_bytes, in_it in, out_it out, T init, std::size_t n,
                    hipStream_t stream) {
+  error::throw_if_exception(temp == nullptr, "exclusive_sum: null temporary storage");
   GRX_HIP_CHECK(rocprim::exclusive_scan(temp, temp_bytes, in, out, init, n, rocprim::plus<T>(), stream));
 }
 

@@ -479,6 +479,54 @@ int main(int argc, char** argv) {
     CHECK(Gd.can_pull() && Gd.has_in_edges());
   }
 
+  // ---- the product's rocPRIM sort call sites at 4 K - 16 K elements ----------------------------
+  // (frontier_t::sort, uniquify's sort, transpose's pair sort: the size range in which round 2's
+  // removed experiment faulted; inputs and device results are dumped for the oracle comparison)
+  {
+    unsigned s = 2024u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+    for (int n : {4096, 6000, 16384}) {
+      std::vector<int> h(n);
+      for (auto& x : h) x = (int)(rnd() % 3000u);
+      frontier_t f;
+      f.reserve(n);
+      f.set_number_of_elements(n);
+      GRX_HIP_CHECK(hipMemcpy(f.data(), h.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      f.sort(sort::order_t::ascending, ctx.stream());
+      auto got = f.to_host();
+      auto want = h;
+      std::sort(want.begin(), want.end());
+      CHECK(got == want);
+      dump_array((std::string("sort_input_") + std::to_string(n)).c_str(), h);
+      dump_array((std::string("sort_output_") + std::to_string(n)).c_str(), got);
+      using problem_type = toy_problem_t<graph_t>;
+      problem_type P(G, mc);
+      toy_enactor_t<problem_type> E(&P, mc);
+      auto* in0 = E.get_input_frontier();
+      in0->reserve(n);
+      in0->set_number_of_elements(n);
+      GRX_HIP_CHECK(hipMemcpy(in0->data(), h.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *mc);
+      auto uq = E.get_input_frontier()->to_host();
+      std::set<int> distinct(h.begin(), h.end());
+      CHECK(uq == std::vector<int>(distinct.begin(), distinct.end()));
+      dump_array((std::string("uniquify_output_") + std::to_string(n)).c_str(), uq);
+    }
+    host_graph sg = make_graph(1500, 4);  // ~ 9 K edges
+    auto s_ap = upload(sg.ap);
+    auto s_aj = upload(sg.aj);
+    auto s_ax = upload(sg.ax);
+    auto SG = graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+        sg.n, sg.n, (int)sg.aj.size(), s_ap.data(), s_aj.data(), s_ax.data());
+    auto T = graph::build::transpose(SG, ctx);
+    CHECK(sg.aj.size() >= 4096 && sg.aj.size() <= 16384);
+    dump_array("transpose_row_offsets", sg.ap);
+    dump_array("transpose_column_indices", sg.aj);
+    dump_array("transpose_result_offsets", T.offsets.to_host());
+    dump_array("transpose_result_indices", T.indices.to_host());
+    dump_array("transpose_result_edge_ids", T.edge_ids.to_host());
+  }
+
   // ---- unsupported variants throw (reference advance.hxx:121-127) ---------------------------
   {
     frontier_t a, b;

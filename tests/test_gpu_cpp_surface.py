@@ -87,4 +87,19 @@ def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
     keep = oracle.filter_keep(d["filter_predicated_input"], lambda v: v == 8 or (v & 1))
     assert d["filter_predicated_output"] == keep.tolist()
     assert d["uniquify_output"] == oracle.uniquify(d["uniquify_input"]).tolist()
+    # the product's rocPRIM sort call sites at 4 K - 16 K elements (the size range of the
+    # round's GPU fault): frontier_t::sort, uniquify, transpose -- run once, checked here
+    for n in (4096, 6000, 16384):
+        src = np.array(d[f"sort_input_{n}"], np.int32)
+        assert d[f"sort_output_{n}"] == np.sort(src, kind="stable").tolist(), n
+        assert d[f"uniquify_output_{n}"] == oracle.uniquify(src).tolist(), n
+    tAp = np.array(d["transpose_row_offsets"], np.int64)
+    tAj = np.array(d["transpose_column_indices"], np.int64)
+    assert 4096 <= len(tAj) <= 16384
+    order = np.argsort(tAj, kind="stable")               # in-edges by destination, source order kept
+    rows = np.repeat(np.arange(len(tAp) - 1), np.diff(tAp))
+    assert d["transpose_result_edge_ids"] == order.tolist()
+    assert d["transpose_result_indices"] == rows[order].tolist()
+    assert d["transpose_result_offsets"] == np.concatenate(
+        [[0], np.cumsum(np.bincount(tAj, minlength=len(tAp) - 1))]).tolist()
     assert d["failures"] == [0]
