@@ -191,6 +191,7 @@ _SIGNATURES = {
                                  C.POINTER(_VP)]),
     "grx_graph_sorted_rows": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     "grx_graph_build_in_edges": (C.c_int, [_VP, _VP]),
+    "grx_graph_hot_first": (C.c_int, [_VP, _VP, C.c_int]),
     "grx_graph_destroy": (C.c_int, [_VP]),
     "grx_graph_info": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int64), C.POINTER(_VP), C.POINTER(_VP),
@@ -505,6 +506,12 @@ class Graph:
     def build_in_edges(self, ctx: "Context") -> "Graph":
         """Attach the transpose (in-edges) of a DIRECTED graph: enables pull / direction-optimised BFS."""
         _check(load_library().grx_graph_build_in_edges(ctx._h, self._h), "grx_graph_build_in_edges")
+        return self
+
+    def hot_first(self, ctx: "Context", enable: bool = True) -> "Graph":
+        """Build now (or drop and disable) the hot-first renumbered copy bfs / sssp run on; labels
+        always come back in this graph's own numbering (include/essentials_amd.h)."""
+        _check(load_library().grx_graph_hot_first(ctx._h, self._h, int(enable)), "grx_graph_hot_first")
         return self
 
     def write_csr_file(self, path: str) -> None:

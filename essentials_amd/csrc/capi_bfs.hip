@@ -22,8 +22,18 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
         if (int rc = ensure_can_pull(ctx, g))
           return rc;
       scoped_options scope(ctx->single(), &o);
-      graph_type G = g->view();
-      problem_type problem(G, source, d_distances, ctx->mc);
+      // the search runs on the hot-first renumbered copy of the graph (reorder.hxx) and delivers
+      // its depths in the caller's numbering; the form that stands for the unchanged reference
+      // client (call_every_edge) and the holes layout keep the caller's graph
+      grx_graph_s* run_on = g;
+      if (!o.call_every_edge && !o.holes_layout)
+        if (grx_graph_s* h = hot_copy(ctx, g))
+          run_on = h;
+      graph_type G = run_on->view();
+      problem_type problem(G, run_on == g ? source : g->hot_rank_of[(std::size_t)source], d_distances,
+                           ctx->mc);
+      if (run_on != g)
+        problem.scatter_to = g->hot_vertex_of.data();
       // push search: one byte per vertex while it runs once 4-byte depths outgrow the eight L2s
       // (GRX_BFS_BYTE_LABELS=0/1 overrides; measurements in DESIGN.md, "Larger graphs")
       if (!o.direction_optimized) {

@@ -5,6 +5,8 @@
  */
 #include "capi_internal.hxx"
 
+#include <gunrock/graph/reorder.hxx>
+
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -91,7 +93,69 @@ int essentials_amd::ensure_can_pull(grx_context_s* ctx, grx_graph_s* g) {
   return GRX_OK;
 }
 
+grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
+  if (g->in_edges)
+    return nullptr;  // attached after the copy was made: the copy has no transpose
+  if (g->hot) {
+    g->hot->symmetry = g->symmetry;  // may have been verified since
+    return g->hot_first == 0 ? nullptr : g->hot.get();
+  }
+  int want = g->hot_first;
+  if (want < 0) {
+    // automatic: graphs whose labels outgrow a CU's LDS image and whose traversal is worth the
+    // second copy of the CSR; a graph with attached in-edges (directed) keeps its numbering -- the
+    // transpose would have to be renumbered too
+    want = g->n_rows == g->n_cols && g->n_rows >= (1 << 16) && g->nnz >= (1 << 20) && !g->in_edges;
+    if (const char* e = std::getenv("GRX_HOT_FIRST"))
+      want = std::atoi(e) != 0 && g->n_rows == g->n_cols && !g->in_edges;
+  }
+  if (!want || g->n_rows < 2)
+    return nullptr;
+  graph_type G = g->view();
+  auto R = graph::build::hot_first(G, ctx->single(), g->max_degree);
+  auto h = std::make_unique<grx_graph_s>();
+  h->n_rows = g->n_rows;
+  h->n_cols = g->n_cols;
+  h->nnz = g->nnz;
+  h->ap = std::move(R.offsets);
+  h->aj = std::move(R.indices);
+  h->ax = std::move(R.values);
+  h->adopt();
+  h->max_degree = g->max_degree;
+  h->max_degree_known = true;
+  h->symmetry = g->symmetry;  // renumbering keeps (a)symmetry
+  h->hot_first = 0;           // a copy has no copy of its own
+  g->hot_rank_of.resize((std::size_t)g->n_rows);
+  GRX_HIP_CHECK(hipMemcpy(g->hot_rank_of.data(), R.rank_of.data(), (std::size_t)g->n_rows * 4,
+                          hipMemcpyDeviceToHost));
+  g->hot_vertex_of = std::move(R.vertex_of);
+  g->hot = std::move(h);
+  return g->hot.get();
+}
+
 extern "C" {
+
+int grx_graph_hot_first(grx_context_t ctx, grx_graph_t g, int enable) {
+  if (!ctx || !g)
+    return invalid("grx_graph_hot_first: NULL argument");
+  return guarded([&] {
+    if (!enable) {
+      g->hot_first = 0;
+      g->hot.reset();
+      g->hot_vertex_of = hip::device_array_t<int32_t>();
+      g->hot_rank_of.clear();
+      g->hot_rank_of.shrink_to_fit();
+      return (int)GRX_OK;
+    }
+    if (g->n_rows != g->n_cols)
+      return unsupported("grx_graph_hot_first: the graph is not square");
+    if (g->in_edges)
+      return unsupported("grx_graph_hot_first: a graph with attached in-edges keeps its numbering");
+    g->hot_first = 1;
+    hot_copy(ctx, g);
+    return (int)GRX_OK;
+  });
+}
 
 int grx_abi_version(void) { return GRX_ABI_VERSION; }
 const char* grx_last_error(void) { return last_error().c_str(); }

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <climits>
 #include <memory>
+#include <vector>
 #include <string>
 
 #include <gunrock/algorithms/algorithms.hxx>
@@ -73,6 +74,10 @@ unsigned long long reduce_max_degree(const int32_t* d_row_offsets, int32_t n_row
 /// transpose, compares it with the column-sorted CSR); GRX_ERR_UNSUPPORTED for a directed graph
 /// (capi_core.hip).  Call inside guarded().
 int ensure_can_pull(grx_context_s* ctx, grx_graph_s* g);
+/// The hot-first renumbered copy of `g` (graph::build::hot_first) the traversals run on, built on
+/// first use; nullptr when the handle or GRX_HOT_FIRST says no, or the graph is too small for it
+/// to matter (capi_core.hip).  Call inside guarded().
+grx_graph_s* hot_copy(grx_context_s* ctx, grx_graph_s* g);
 }  // namespace essentials_amd
 
 struct grx_graph_s {
@@ -102,6 +107,13 @@ struct grx_graph_s {
   // PULL traversal asks (essentials_amd::ensure_can_pull)
   enum symmetry_t { symmetry_unknown = 0, symmetric = 1, asymmetric = 2 };
   mutable int symmetry = symmetry_unknown;
+  // Hot-first renumbered copy (include/gunrock/graph/reorder.hxx) that grx_bfs / grx_sssp run on;
+  // labels are delivered in the caller's numbering.  -1: automatic (GRX_HOT_FIRST, size), 0: off,
+  // 1: on (grx_graph_hot_first).
+  int hot_first = -1;
+  std::unique_ptr<grx_graph_s> hot;
+  gunrock::hip::device_array_t<int32_t> hot_vertex_of;  // device: caller's id of a renumbered vertex
+  std::vector<int32_t> hot_rank_of;                     // host: renumbered id of a caller's vertex
 
   essentials_amd::graph_type view() const {
     using namespace gunrock;

@@ -29,8 +29,17 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       using problem_type = clients::sssp_problem_t<graph_type>;
       using enactor_type = clients::sssp_enactor_t<problem_type, lb>;
       scoped_options scope(ctx->single(), &o);
-      graph_type G = g->view();
-      problem_type problem(G, source, d_distances, ctx->mc);
+      // hot-first renumbered copy, distances delivered in the caller's numbering (see grx_bfs); the
+      // reference's two-pass formulation and the every-edge form keep the caller's graph
+      grx_graph_s* run_on = g;
+      if (!o.sssp_two_pass && !o.call_every_edge && !o.holes_layout)
+        if (grx_graph_s* h = hot_copy(ctx, g))
+          run_on = h;
+      graph_type G = run_on->view();
+      problem_type problem(G, run_on == g ? source : g->hot_rank_of[(std::size_t)source], d_distances,
+                           ctx->mc);
+      if (run_on != g)
+        problem.scatter_to = g->hot_vertex_of.data();
       // one 64-bit label per vertex (one RMW per improvement) while 8 bytes per vertex stay
       // cache-sized; beyond that the doubled label footprint costs more lookups that miss than the
       // saved RMWs are worth.  Measured crossover on R-MAT (tools/sssp_packed_vs_words.py, mean

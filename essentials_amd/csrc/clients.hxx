@@ -61,14 +61,25 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
   // written when the run ends or when level 254 is reached (the search then goes on in it).
   bool byte_labels = false;
   hip::device_array_t<unsigned> bytes;
+  // The graph is a renumbered copy of the caller's (graph::build::hot_first): `source` is in the
+  // graph's numbering, the search runs in an array of its own and deliver() hands every label to
+  // the caller's array in the caller's numbering, depth[scatter_to[v]] = label of v.
+  const vertex_t* scatter_to = nullptr;
+  hip::device_array_t<vertex_t> own_labels;
 
   bfs_problem_t(graph_t& G, vertex_t _source, vertex_t* _depth,
                 std::shared_ptr<gcuda::multi_context_t> ctx)
       : gunrock::problem_t<graph_t>(G, ctx), source(_source), depth(_depth) {}
 
+  /// The 4-byte array the search runs in (the graph's numbering).
+  vertex_t* labels() { return scatter_to ? own_labels.data() : depth; }
+
   void init() override {
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
     if (byte_labels)
-      bytes.resize(((std::size_t)this->get_graph().get_number_of_vertices() + 3) / 4);
+      bytes.resize((n + 3) / 4);
+    else if (scatter_to)
+      own_labels.resize(n);
   }
   void reset() override {
     auto ctx = this->get_single_context();
@@ -83,7 +94,7 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
           },
           ctx->stream());
     } else {
-      vertex_t* d = depth;
+      vertex_t* d = labels();
       hip::for_each_index(
           n, [d, s] __device__(std::size_t i) {
             d[i] = (vertex_t)i == s ? vertex_t(0) : std::numeric_limits<vertex_t>::max();
@@ -92,14 +103,16 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
     }
     log = level_log_t();
   }
-  /// Byte form: write the caller's depth array (one pass) and continue / end in it.
+  /// Byte form: write the 4-byte array (one pass) and continue / end in it.
   void unpack() {
     if (!byte_labels)
       return;
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    if (scatter_to)
+      own_labels.resize(n);
     const unsigned* w = bytes.data();
-    vertex_t* d = depth;
+    vertex_t* d = labels();
     hip::for_each_index(
         n, [w, d] __device__(std::size_t i) {
           const unsigned b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
@@ -107,6 +120,30 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
         },
         ctx->stream());
     byte_labels = false;
+  }
+  /// End of a run (inside the timed enact()): every label in the caller's array and numbering.
+  void deliver() {
+    if (!scatter_to) {
+      unpack();
+      return;
+    }
+    auto ctx = this->get_single_context();
+    const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
+    const vertex_t* to = scatter_to;
+    vertex_t* d = depth;
+    if (byte_labels) {
+      const unsigned* w = bytes.data();
+      hip::for_each_index(
+          n, [w, d, to] __device__(std::size_t i) {
+            const unsigned b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+            d[to[i]] = b == 0xFFu ? std::numeric_limits<vertex_t>::max() : (vertex_t)b;
+          },
+          ctx->stream());
+      byte_labels = false;
+    } else {
+      const vertex_t* l = own_labels.data();
+      hip::for_each_index(n, [l, d, to] __device__(std::size_t i) { d[to[i]] = l[i]; }, ctx->stream());
+    }
   }
 };
 
@@ -133,7 +170,7 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     return base_t::is_converged(context);
   }
 
-  void finalize(gcuda::multi_context_t&) override { this->get_problem()->unpack(); }
+  void finalize(gcuda::multi_context_t&) override { this->get_problem()->deliver(); }
 
   /// One level.  `visit` discovers, `has_depth` is its pure "already discovered" test.
   template <typename visit_t, typename has_depth_t>
@@ -167,10 +204,10 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     P->log.note(E->get_input_frontier()->get_number_of_elements(),
                 E->get_input_frontier()->work_hint());
 
-    vertex_t* depth = P->depth;
     const vertex_t next_level = this->iteration + 1;
     if (P->byte_labels && next_level >= 255)
-      P->unpack();  // a byte cannot hold this level: go on in the caller's array
+      P->unpack();  // a byte cannot hold this level: go on in the 4-byte array
+    vertex_t* depth = P->labels();
     if (P->byte_labels) {
       unsigned* words = P->bytes.data();
       const unsigned level = (unsigned)next_level;
@@ -253,6 +290,8 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
     return base_t::is_converged(context);
   }
 
+  void finalize(gcuda::multi_context_t&) override { this->get_problem()->deliver(); }
+
   void loop(gcuda::multi_context_t& context) override {
     auto E = this->get_enactor();
     auto P = this->get_problem();
@@ -261,7 +300,7 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
     frontier_t* in = E->get_input_frontier();
     P->log.note(in->get_number_of_elements());
 
-    vertex_t* depth = P->depth;
+    vertex_t* depth = P->labels();
     const vertex_t next_level = this->iteration + 1;
     const std::size_t n_vertices = (std::size_t)G.get_number_of_vertices();
     const std::size_t n_f = in->get_number_of_elements();
@@ -358,6 +397,11 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   // is not below that bound without touching the label (section 5 of DESIGN.md: the wide SSSP
   // iterations run at the fabric's rate of 128-byte label lines).
   hip::device_array_t<unsigned short> bound16;
+  // renumbered graph (see bfs_problem_t): distances are delivered as distance[scatter_to[v]]
+  const vertex_t* scatter_to = nullptr;
+  hip::device_array_t<weight_t> own_distance;
+  /// The float array the two-word form runs in (the graph's numbering).
+  weight_t* run_distance() { return scatter_to ? own_distance.data() : distance; }
 
   /// float <-> 32 bits whose UNSIGNED order is the float order (negative values included).
   __host__ __device__ static unsigned ordered_bits(weight_t x) {
@@ -383,6 +427,8 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
       packed.resize(n);
     else
       stamp.resize(n);
+    if (!packed_labels && scatter_to)
+      own_distance.resize(n);
 #ifdef GRX_SSSP_DIAG
     diag.resize(64 * 16);
     diag.zero();
@@ -416,7 +462,7 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
           n, [p, s, zero, far] __device__(std::size_t i) { p[i] = (vertex_t)i == s ? zero : far; },
           ctx->stream());
     } else {
-      weight_t* d = distance;
+      weight_t* d = run_distance();
       int* st = stamp.data();
       hip::for_each_index(
           n, [d, st, s] __device__(std::size_t i) {
@@ -427,17 +473,27 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
     }
     log = level_log_t();
   }
-  /// Packed form: write the caller's distance array (one pass, on the context's stream).
+  /// End of a run: the caller's distance array in the caller's numbering (one pass, on the
+  /// context's stream; nothing to do for the two-word form on the caller's own numbering).
   void unpack() {
-    if (!packed_labels)
-      return;
     auto ctx = this->get_single_context();
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
     const unsigned long long* p = packed.data();
     weight_t* d = distance;
-    hip::for_each_index(
-        n, [p, d] __device__(std::size_t i) { d[i] = from_ordered_bits((unsigned)(p[i] >> 32)); },
-        ctx->stream());
+    const vertex_t* to = scatter_to;
+    if (packed_labels) {
+      if (to)
+        hip::for_each_index(
+            n, [p, d, to] __device__(std::size_t i) { d[to[i]] = from_ordered_bits((unsigned)(p[i] >> 32)); },
+            ctx->stream());
+      else
+        hip::for_each_index(
+            n, [p, d] __device__(std::size_t i) { d[i] = from_ordered_bits((unsigned)(p[i] >> 32)); },
+            ctx->stream());
+    } else if (to) {
+      const weight_t* own = own_distance.data();
+      hip::for_each_index(n, [own, d, to] __device__(std::size_t i) { d[to[i]] = own[i]; }, ctx->stream());
+    }
   }
 };
 
@@ -476,7 +532,7 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
     P->log.note(E->get_input_frontier()->get_number_of_elements(),
                 E->get_input_frontier()->work_hint());
 
-    weight_t* distance = P->distance;
+    weight_t* distance = P->run_distance();
     int* stamp = P->stamp.data();
     const int round = this->iteration;
 

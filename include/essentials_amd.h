@@ -197,6 +197,17 @@ int grx_graph_sorted_rows(grx_context_t ctx, grx_graph_t g, grx_graph_t* out);
  * undirected (symmetric CSR = its own transpose).  Reference counterpart: the csc view of
  * graph::build::from_csr (graph/detail/build.hxx:96-113), which it cannot combine with csr. */
 int grx_graph_build_in_edges(grx_context_t ctx, grx_graph_t g);
+/* Hot-first numbering (engine data layout, no reference counterpart; the reference's views keep
+ * the loader's numbering, graph/build.hxx:26-52).  grx_bfs / grx_sssp run on a copy of the graph
+ * whose vertices are renumbered in descending order of out-degree
+ * (include/gunrock/graph/reorder.hxx) and deliver their labels in the CALLER's numbering: sources
+ * in, labels out, nothing else changes at this boundary.  The copy (a second CSR + 8 bytes per
+ * vertex) is built on the first traversal of a square graph of >= 2^16 vertices and >= 2^20 edges
+ * without attached in-edges (GRX_HOT_FIRST=0/1 overrides the size rule); enable = 1 builds it now
+ * for any square graph, enable = 0 drops it and keeps this handle on its own numbering.  The
+ * options that stand for the unchanged reference clients (call_every_edge, sssp_two_pass) and the
+ * holes layout always run on the caller's numbering. */
+int grx_graph_hot_first(grx_context_t ctx, grx_graph_t g, int enable);
 int grx_graph_destroy(grx_graph_t g);
 int grx_graph_info(grx_graph_t g, int32_t* n_rows, int32_t* n_cols, int64_t* nnz,
                    const int32_t** d_row_offsets, const int32_t** d_col, const float** d_val);

@@ -592,3 +592,65 @@ def test_sssp_fractional_weights_within_one_ulp(ea, ctx, torch, oracle):
         assert ((got < 3e38) == finite).all()
         ulp = np.abs(got[finite].view(np.int32).astype(np.int64) - want[finite].view(np.int32).astype(np.int64))
         assert ulp.max() <= 1, (lb, int(ulp.max()))
+
+
+# ---------------------------------------------------------------------------
+# hot-first numbering (include/gunrock/graph/reorder.hxx): labels come back in the CALLER's ids
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,seed", [(10, 1), (14, 3)])
+def test_hot_first_numbering_changes_nothing(ea, ctx, oracle, monkeypatch, scale, seed):
+    """grx_graph_hot_first(1): BFS (4-byte, byte and direction-optimised labels) and SSSP (packed
+    and two-word labels) on the renumbered copy deliver exactly the oracle's labels per CALLER id;
+    the forms that stand for the unchanged reference clients keep the caller's graph."""
+    g = ea.Graph.rmat(ctx, scale, 16, seed, 7)
+    Ap, Aj, Ax = g.to_host()
+    deg = np.diff(Ap)
+    rng = np.random.default_rng(11 + SEED_OFFSET)
+    sources = [0] + [int(s) for s in rng.choice(np.flatnonzero(deg > 0), 3, replace=False)]
+    g.hot_first(ctx, True)
+    for s in sources:
+        want_d, _ = oracle.bfs_heap(Ap, Aj, s)
+        want_w, _ = oracle.sssp_heap(Ap, Aj, Ax, s)
+        for env in ({}, {"GRX_BFS_BYTE_LABELS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            d, st = ea.bfs(ctx, g, s)
+            assert (host(d) == want_d).all(), (s, env)
+            assert st.edges_traversed == int(deg[want_d != INF_I].sum())
+            for k in env:
+                monkeypatch.delenv(k)
+        d, _ = ea.bfs(ctx, g, s, options=ea.Options(direction_optimized=True))
+        assert (host(d) == want_d).all(), (s, "direction optimised")
+        for lb in ("block_mapped", "merge_path", "bucketing"):
+            d, _ = ea.bfs(ctx, g, s, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+            assert (host(d) == want_d).all(), (s, lb)
+        for packed in ("1", "0"):
+            monkeypatch.setenv("GRX_SSSP_PACKED", packed)
+            w, _ = ea.sssp(ctx, g, s)
+            assert (host(w).view(np.uint32) == want_w.view(np.uint32)).all(), (s, packed)
+        monkeypatch.delenv("GRX_SSSP_PACKED")
+        w, _ = ea.sssp(ctx, g, s, options=ea.Options(sssp_two_pass=True))
+        assert (host(w).view(np.uint32) == want_w.view(np.uint32)).all()
+        d, _ = ea.bfs(ctx, g, s, options=ea.Options(call_every_edge=True))
+        assert (host(d) == want_d).all()
+    # dropping the copy changes nothing either
+    g.hot_first(ctx, False)
+    d, _ = ea.bfs(ctx, g, sources[1])
+    assert (host(d) == oracle.bfs_heap(Ap, Aj, sources[1])[0]).all()
+
+
+def test_hot_first_renumbering_is_a_degree_sorted_isomorphism(ea, ctx, torch):
+    """The renumbered copy itself (C++ surface: graph::build::hot_first through the handle): BFS
+    depths of the copy's own numbering are a permutation of the caller's, and the wide-level forms
+    (settled bitmap, SSSP bound image) that read the low ids see the heaviest vertices there."""
+    g = ea.Graph.rmat(ctx, 16, 16, 1, 7)          # 65,536 vertices, ~2 M edges: the automatic rule applies
+    Ap = g.offsets_to_host()
+    d0, st0 = ea.bfs(ctx, g, 0)                   # automatic: runs on the copy
+    g.hot_first(ctx, False)
+    d1, st1 = ea.bfs(ctx, g, 0)                   # caller's numbering
+    assert torch.equal(d0, d1) and st0.edges_traversed == st1.edges_traversed
+    assert st0.frontier_slots == st1.frontier_slots
+    w0, _ = ea.sssp(ctx, g, 5)
+    g.hot_first(ctx, True)
+    w1, _ = ea.sssp(ctx, g, 5)
+    assert torch.equal(w0.view(torch.int32), w1.view(torch.int32))
