@@ -348,19 +348,37 @@ void execute(graph_t& G,
       // in its LDS (advance_kernels.hxx: expand_settled_kernel)
       if (use_settled) {
         auto kernel = k::expand_settled_kernel<input_type, output_type, graph_t, operator_t, vertex_t, edge_t>;
-        if (!op.settled.bits)  // a predicate only: no bitmap to keep in LDS
+        if (!op.settled.bits)  // a predicate only: no image to keep in LDS
           op.settled.limit = 0;
         const std::size_t lds = op.settled.limit > 0 ? op.lds_bytes() : 16;
-        static std::atomic<std::size_t> allowed{0};  // per instantiation: the opt-in is sticky
-        if (allowed.load(std::memory_order_relaxed) < lds) {
-          GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(settled_max_ids / 8)));
-          allowed.store(settled_max_ids / 8, std::memory_order_relaxed);
+        // dynamic LDS beyond 64 KB needs an opt-in, per device and instantiation; the kernel's static
+        // LDS + the image must fit the CU (a wide edge_t makes the static part larger): if not, the
+        // fused form below expands this level with the functor called for every edge
+        struct fit_t {
+          std::size_t static_bytes = 0, allowed = 0;
+          bool known = false;
+        };
+        static fit_t fits[64];  // by device ordinal
+        fit_t& fit = fits[context.ordinal() & 63];
+        if (!fit.known) {
+          hipFuncAttributes fa;
+          GRX_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)));
+          fit.static_bytes = fa.sharedSizeBytes;
+          fit.known = true;
         }
-        kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
-            G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors);
-        expanded = true;
+        const std::size_t cu_lds = 160u << 10;
+        if (fit.static_bytes + lds <= cu_lds) {
+          if (fit.allowed < lds) {
+            GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(cu_lds - fit.static_bytes)));
+            fit.allowed = cu_lds - fit.static_bytes;
+          }
+          kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
+              G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors);
+          GRX_HIP_CHECK(hipGetLastError());
+          expanded = true;
+        }
       }
     }
     if (!expanded) {
