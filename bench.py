@@ -37,6 +37,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the OpenMP CPU baseline m
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver: dmabuf IPC only (RCCL)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6300.0  # what a copy kernel achieves (same guide): the fabric rate measured bytes run at
 
 
 def parse():
@@ -105,6 +106,28 @@ def cpu_baseline(Ap, Aj, Ax, algo):
     return {"value": edges / (ms * 1e-3) / 1e6, "unit": "MTEPS", "cores": 1, "kind": kind,
             "sample": f"one {algo} from source 0 on the same R-MAT graph, search loops only "
                       f"({ms:.0f} ms of {time.time() - t0:.0f} s wall)"}
+
+
+def cpu_baseline_from_n1(a):
+    """The CPU baseline is timed at N = 1 only; an N > 1 line carries that figure: from the N = 1
+    run of the same session on this box when there was one (it leaves gpurun_out/cpu_baseline_n1.json),
+    else from the committed bench line of the round (another box of the same type)."""
+    for path, origin in ((os.path.join(ROOT, "gpurun_out", "cpu_baseline_n1.json"), "N=1 run of this session"),
+                         (os.path.join(ROOT, "profiles", "latest_bench_line.json"), "committed profiles/latest_bench_line.json")):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        base = rec.get("cpu_baseline")
+        if not base:
+            continue
+        if "scale" in rec:
+            same = rec["scale"] == a.scale
+        else:
+            same = ("scale-%d " % a.scale) in rec.get("config", {}).get("workload", "")
+        if same:
+            return dict(base, origin=origin, strong=rec.get("cpu_baseline_strong"))
+    return None
 
 
 def pagerank_leg(ea, ctx, a) -> dict:
@@ -177,7 +200,12 @@ def attach_pmc(out: dict, a, world: int) -> None:
         roof["traffic"] = rec["bytes_per_traversal"]
         roof["traffic_detail"] = dict(rec, **stamp)
         if roof.get("kernel_ms"):
-            roof["measured_frac"] = rec["bytes_per_traversal"] / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            gbps = rec["bytes_per_traversal"] / (roof["kernel_ms"] * 1e-3) / 1e9
+            roof["measured_frac"] = gbps / HBM_PEAK_GBPS
+            roof["measured_frac_of_copy_rate"] = gbps / HBM_COPY_GBPS
+            roof["measured_note"] = ("traffic = L2 <-> fabric requests by size (rocprofv3 --pmc TCC_EA0_*): it "
+                                     "includes Infinity-Cache hits; measured_frac is against the 8 TB/s peak, "
+                                     "measured_frac_of_copy_rate against the ~6.3 TB/s a copy achieves")
     l2 = pmc.get("l2", {})
     if out.get("roofline") is not None:
         out["roofline"]["l2_busy_frac"] = l2.get("busy_frac_bfs_advance")
@@ -189,8 +217,9 @@ def attach_pmc(out: dict, a, world: int) -> None:
             if rec and form in pr and "roofline" in pr[form]:
                 pr[form]["roofline"]["traffic"] = rec["bytes_per_iteration"]
                 pr[form]["roofline"]["traffic_detail"] = dict(rec, **stamp)
-                pr[form]["roofline"]["measured_frac"] = (
-                    rec["bytes_per_iteration"] / (pr[form]["ms_per_iteration"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                gbps = rec["bytes_per_iteration"] / (pr[form]["ms_per_iteration"] * 1e-3) / 1e9
+                pr[form]["roofline"]["measured_frac"] = gbps / HBM_PEAK_GBPS
+                pr[form]["roofline"]["measured_frac_of_copy_rate"] = gbps / HBM_COPY_GBPS
 
 
 def free_port() -> int:
@@ -370,6 +399,8 @@ def main():
         if runner.exchange_note:
             out["config"]["exchange_note"] = runner.exchange_note
         out["verify"] = runner.verify(sources[a.warmup])
+    if world == 1 and a.algo == "bfs+sssp":
+        out["reference_clients"] = runner.reference_clients(sources[a.warmup:a.warmup + a.steps], lb)
     if world == 1 and "bfs" in a.algo:
         out["bfs_direction_optimized"] = runner.bfs_direction_optimized(
             sources[a.warmup:a.warmup + min(a.steps, 8)], lb)
@@ -384,8 +415,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Ap, Aj, Ax, a.algo)
             if "bfs" in a.algo:
                 out["cpu_baseline_strong"] = cpu_baseline_strong(Ap, Aj)
+            try:   # the N > 1 lines of the same session carry it as cpu_baseline_n1
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "cpu_baseline_n1.json"), "w") as f:
+                    json.dump({"scale": a.scale, "algo": a.algo, "cpu_baseline": out["cpu_baseline"],
+                               "cpu_baseline_strong": out.get("cpu_baseline_strong")}, f)
+            except OSError:
+                pass
         else:
             out["cpu_baseline"] = None
+            if world > 1:   # timed on the host cores at N = 1 only: carry that run's figures
+                out["cpu_baseline_n1"] = cpu_baseline_from_n1(a)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

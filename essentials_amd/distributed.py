@@ -184,6 +184,34 @@ class SingleRunner:
                 "edges_traversed": best.edges_traversed, "vertices_reached": best.vertices_reached,
                 "kernel_gteps": best.edges_traversed / (best.advance_kernel_ms * 1e-3) / 1e9}
 
+    def reference_clients(self, sources, lb) -> dict:
+        """What the reference's UNCHANGED bfs.hxx + sssp.hxx get from this engine, over the same
+        sources as the timed steps (outside the timed region): the BFS whose functor runs for every
+        edge (no settled hint to give; grx_options.call_every_edge) and the two-pass SSSP (advance +
+        bypass filter with the racy stamp test, algorithms/sssp.hxx:110-144; grx_options.sssp_two_pass),
+        both on the caller's vertex numbering (no hot-first copy: an unchanged client traverses the
+        graph_t it was given).  tests/test_gpu_reference_clients.py runs the real headers, compiled
+        in place, through the same engine; these two options are their formulation behind the C ABI."""
+        b_ms, s_ms, edges = [], [], 0
+        ob = ea.Options(load_balance=lb, call_every_edge=True)
+        os_ = ea.Options(load_balance=lb, sssp_two_pass=True)
+        for s in sources:
+            _, st = ea.bfs(self.ctx, self.g, s, self.depth, ob)
+            self.runs["bfs_call_every_edge"] += 1
+            b_ms.append(st.elapsed_ms)
+            edges += st.edges_traversed
+            _, st = ea.sssp(self.ctx, self.g, s, self.dist, os_)
+            self.runs["sssp_two_pass"] += 1
+            s_ms.append(st.elapsed_ms)
+            edges += st.edges_traversed
+        step = (sum(b_ms) + sum(s_ms)) / len(sources)
+        return {"bfs_every_edge_enact_ms": sum(b_ms) / len(b_ms),
+                "sssp_two_pass_enact_ms": sum(s_ms) / len(s_ms),
+                "step_ms": step, "mteps": edges / ((sum(b_ms) + sum(s_ms)) * 1e-3) / 1e6,
+                "sources": len(sources),
+                "note": "enact() time only (the headline's ms_per_step also holds ~0.2 ms per step outside "
+                        "enact()); caller's numbering, no settled hint, two-pass SSSP"}
+
     def bfs_direction_optimized(self, sources, lb) -> dict:
         """SURVEY 8(f) rank 4 (beyond the reference, whose advance throws for pull): the same
         traversals with the wide levels pulled.  Same depths; reported beside the headline."""
