@@ -24,7 +24,13 @@ FLT_UNREACHED = float(np.finfo(np.float32).max)
 
 
 class EngineError(RuntimeError):
-    """A C-ABI call failed (the C++ surface threw gunrock::error::exception_t)."""
+    """A C-ABI call failed (the C++ surface threw gunrock::error::exception_t).  `code` is the
+    grx_status: -1 invalid argument, -2 runtime, -3 unsupported, -4 a peer rank's superstep failed,
+    -5 a superstep's gather timed out (exit without synchronising the context)."""
+    code = 0
+
+
+ERR_PEER, ERR_TIMEOUT = -4, -5
 
 
 class LoadBalance(enum.IntEnum):
@@ -86,7 +92,8 @@ class _PartitionedStats(C.Structure):
     _fields_ = [("elapsed_ms", C.c_float), ("supersteps", C.c_int32), ("collectives", C.c_int32),
                 ("bitmap_supersteps", C.c_int32), ("allreduce_supersteps", C.c_int32),
                 ("iterations", C.c_int32), ("last_error", C.c_float),
-                ("pairs_exchanged", C.c_int64), ("bytes_sent", C.c_int64)]
+                ("pairs_exchanged", C.c_int64), ("bytes_sent", C.c_int64),
+                ("large_gather_supersteps", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -209,6 +216,8 @@ _SIGNATURES = {
                                C.POINTER(C.c_int64)]),
     "grx_graph_partition": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]),
+    "grx_graph_partition_hot_first": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP),
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "grx_partitioned_expand": (C.c_int, [_VP, _VP, C.POINTER(_Options), C.c_int32, _VP, C.c_int32,
                                          _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64,
                                          C.POINTER(C.c_int64)]),
@@ -263,7 +272,9 @@ def load_library():
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load_library().grx_last_error()
-        raise EngineError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+        err = EngineError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+        err.code = rc
+        raise err
 
 
 def _ptr(t) -> Optional[int]:

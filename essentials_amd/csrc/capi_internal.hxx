@@ -62,6 +62,11 @@ struct grx_context_s {
   std::shared_ptr<gunrock::gcuda::multi_context_t> mc;
   int device = 0;
   unsigned long long pending_sequence = 0;  // counters hand-off of an enqueue-only call
+  // partitioned supersteps: what the job found in the PREVIOUS superstep (all ranks; -1 unknown) --
+  // the size class of the frontier the next grx_partitioned_step expands -- and the settled bitmap
+  // its wide BFS supersteps rebuild (operators/settled.hxx)
+  long long superstep_finds_hint = -1;
+  gunrock::operators::advance::settled_filter_t<int32_t> superstep_settled;
   gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
 };
 
@@ -114,6 +119,9 @@ struct grx_graph_s {
   std::unique_ptr<grx_graph_s> hot;
   gunrock::hip::device_array_t<int32_t> hot_vertex_of;  // device: caller's id of a renumbered vertex
   std::vector<int32_t> hot_rank_of;                     // host: renumbered id of a caller's vertex
+  // this handle IS a slice of a renumbered copy (grx_graph_partition_hot_first): the two arrays
+  // above are the permutations grx_partitioned_run translates with
+  bool renumbered_slice = false;
 
   essentials_amd::graph_type view() const {
     using namespace gunrock;

@@ -225,42 +225,83 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
 
 extern "C" {
 
+namespace {
+/// Rank `rank`'s slice of `full` (rows outside [lo, hi) empty, global ids).
+std::unique_ptr<grx_graph_s> slice_of(grx_graph_s* full, int rank, int world, int32_t& lo, int32_t& hi) {
+  const int32_t n = full->n_rows;
+  std::vector<int32_t> ap((std::size_t)n + 1);
+  GRX_HIP_CHECK(hipMemcpy(ap.data(), full->d_ap, ap.size() * 4, hipMemcpyDeviceToHost));
+  // edge-balanced split points: first row whose offset reaches k * E / world
+  auto split = [&](int k) -> int32_t {
+    if (k <= 0) return 0;
+    if (k >= world) return n;
+    const int64_t target = (int64_t)ap[n] * k / world;
+    return (int32_t)(std::lower_bound(ap.begin(), ap.end(), (int32_t)target) - ap.begin());
+  };
+  lo = split(rank);
+  hi = split(rank + 1);
+  if (lo > n) lo = n;
+  if (hi > n) hi = n;
+  if (hi < lo) hi = lo;
+  auto g = std::make_unique<grx_graph_s>();
+  g->n_rows = n;
+  g->n_cols = full->n_cols;
+  g->nnz = (int64_t)ap[hi] - ap[lo];
+  g->ap.resize((std::size_t)n + 1);
+  g->aj.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+  g->ax.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
+  slice_offsets_kernel<<<1024, 256>>>(full->d_ap, n, lo, hi, g->ap.data());
+  GRX_HIP_CHECK(hipGetLastError());
+  if (g->nnz) {
+    GRX_HIP_CHECK(hipMemcpy(g->aj.data(), full->d_aj + ap[lo], (std::size_t)g->nnz * 4,
+                            hipMemcpyDeviceToDevice));
+    GRX_HIP_CHECK(hipMemcpy(g->ax.data(), full->d_ax + ap[lo], (std::size_t)g->nnz * 4,
+                            hipMemcpyDeviceToDevice));
+  }
+  GRX_HIP_CHECK(hipDeviceSynchronize());
+  g->adopt();
+  g->hot_first = 0;  // a slice is traversed as it is
+  return g;
+}
+}  // namespace
+
 int grx_graph_partition(grx_graph_t full, int rank, int world, grx_graph_t* out,
                         int32_t* row_begin, int32_t* row_end) {
   if (!full || !out || world < 1 || rank < 0 || rank >= world)
     return invalid("grx_graph_partition: bad arguments");
   return guarded([&] {
-    const int32_t n = full->n_rows;
-    std::vector<int32_t> ap((std::size_t)n + 1);
-    GRX_HIP_CHECK(hipMemcpy(ap.data(), full->d_ap, ap.size() * 4, hipMemcpyDeviceToHost));
-    // edge-balanced split points: first row whose offset reaches k * E / world
-    auto split = [&](int k) -> int32_t {
-      if (k <= 0) return 0;
-      if (k >= world) return n;
-      const int64_t target = (int64_t)ap[n] * k / world;
-      return (int32_t)(std::lower_bound(ap.begin(), ap.end(), (int32_t)target) - ap.begin());
-    };
-    int32_t lo = split(rank), hi = split(rank + 1);
-    if (lo > n) lo = n;
-    if (hi > n) hi = n;
-    if (hi < lo) hi = lo;
-    auto g = std::make_unique<grx_graph_s>();
-    g->n_rows = n;
-    g->n_cols = full->n_cols;
-    g->nnz = (int64_t)ap[hi] - ap[lo];
-    g->ap.resize((std::size_t)n + 1);
-    g->aj.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
-    g->ax.resize((std::size_t)std::max<int64_t>(g->nnz, 1));
-    slice_offsets_kernel<<<1024, 256>>>(full->d_ap, n, lo, hi, g->ap.data());
-    GRX_HIP_CHECK(hipGetLastError());
-    if (g->nnz) {
-      GRX_HIP_CHECK(hipMemcpy(g->aj.data(), full->d_aj + ap[lo], (std::size_t)g->nnz * 4,
-                              hipMemcpyDeviceToDevice));
-      GRX_HIP_CHECK(hipMemcpy(g->ax.data(), full->d_ax + ap[lo], (std::size_t)g->nnz * 4,
-                              hipMemcpyDeviceToDevice));
+    int32_t lo = 0, hi = 0;
+    auto g = slice_of(full, rank, world, lo, hi);
+    if (row_begin) *row_begin = lo;
+    if (row_end) *row_end = hi;
+    *out = g.release();
+    return (int)GRX_OK;
+  });
+}
+
+int grx_graph_partition_hot_first(grx_context_t ctx, grx_graph_t full, int rank, int world,
+                                  grx_graph_t* out, int32_t* row_begin, int32_t* row_end) {
+  if (!ctx || !full || !out || world < 1 || rank < 0 || rank >= world)
+    return invalid("grx_graph_partition_hot_first: bad arguments");
+  return guarded([&] {
+    if (full->n_rows != full->n_cols || full->in_edges)
+      return unsupported("grx_graph_partition_hot_first: needs a square graph without attached in-edges");
+    const int before = full->hot_first;
+    if (!full->hot) {
+      full->hot_first = 1;
+      hot_copy(ctx, full);
+      full->hot_first = before;  // the handle's own traversals keep their rule
     }
+    error::throw_if_exception(!full->hot, "grx_graph_partition_hot_first: no renumbered copy");
+    int32_t lo = 0, hi = 0;
+    auto g = slice_of(full->hot.get(), rank, world, lo, hi);
+    // the slice carries both permutations: grx_partitioned_run translates at its boundary
+    g->hot_rank_of = full->hot_rank_of;
+    g->hot_vertex_of.resize((std::size_t)full->n_rows);
+    GRX_HIP_CHECK(hipMemcpy(g->hot_vertex_of.data(), full->hot_vertex_of.data(), (std::size_t)full->n_rows * 4,
+                            hipMemcpyDeviceToDevice));
     GRX_HIP_CHECK(hipDeviceSynchronize());
-    g->adopt();
+    g->renumbered_slice = true;
     if (row_begin) *row_begin = lo;
     if (row_end) *row_end = hi;
     *out = g.release();
@@ -454,9 +495,23 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
                                                            edge_t const& e, weight_t const& w) -> bool {
         return next_level < math::atomic::min(&depth[dst], next_level);
       };
-      operators::advance::block_mapped::enqueue_packed(G, visit, d_frontier, bound, count_dev,
-                                                       (unsigned long long)local->nnz, d_scratch,
-                                                       (std::size_t)scratch_capacity, sc);
+      // a wide superstep (the job found many vertices in the previous one): the single-GPU search's
+      // wide-level form -- settled bitmap of the low ids in LDS, batched depth look-ups, the functor
+      // on packed survivors (operators/settled.hxx); the frontier length stays on the device
+      bool wide = false;
+      if (sc.options().settled_filter && ctx->superstep_finds_hint >= (long long)sc.options().fused_min_slots) {
+        auto has_depth = [depth] __device__(vertex_t const& v) -> bool {
+          return depth[v] != std::numeric_limits<vertex_t>::max();
+        };
+        ctx->superstep_settled.rebuild((std::size_t)local->n_rows, has_depth, sc);
+        wide = operators::advance::block_mapped::enqueue_packed_settled(
+            G, operators::advance::with_settled(visit, ctx->superstep_settled.view(), has_depth), d_frontier,
+            bound, count_dev, (unsigned long long)local->nnz, d_scratch, (std::size_t)scratch_capacity, sc);
+      }
+      if (!wide)
+        operators::advance::block_mapped::enqueue_packed(G, visit, d_frontier, bound, count_dev,
+                                                         (unsigned long long)local->nnz, d_scratch,
+                                                         (std::size_t)scratch_capacity, sc);
     } else {
       float* dist = reinterpret_cast<float*>(d_labels);
       // one copy of an improved vertex per superstep (the first improver wins the exchange on

@@ -32,6 +32,9 @@ struct grx_partitioned_s {
   hip::device_array_t<int64_t> send, recv, recv_big, bits, recv_bits;
   hip::device_array_t<unsigned long long> fcount;
   hip::device_array_t<float> snapshot;
+  // plan over a slice of a renumbered copy (grx_graph_partition_hot_first): the replica the
+  // supersteps run on; the caller's array is written once, at the end of a run
+  hip::device_array_t<int32_t> renumbered_labels;
   // PageRank
   hip::device_array_t<float> scale, partial;
   // gathered per-rank counts land here (pinned): [0, world) counts, [world] sequence number
@@ -59,6 +62,13 @@ __global__ void __launch_bounds__(256)
       frontier[0] = source;
     *fcount = mine ? 1ull : 0ull;
   }
+}
+
+/// End of a run on a renumbered slice: out[vertex_of[r]] = labels[r] (4-byte labels of either kind).
+__global__ void __launch_bounds__(256)
+    deliver_kernel(const int32_t* labels, const int32_t* vertex_of, int64_t n, int32_t* out) {
+  for (int64_t r = blockIdx.x * 256ll + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+    out[vertex_of[r]] = labels[r];
 }
 
 /// Hand the gathered per-rank find counts (word 0 of every rank's slot) to the host through pinned
@@ -102,15 +112,42 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+/// The gathered counts did not arrive in time: a peer is gone or stuck inside the collective.
+struct superstep_timeout_t : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+long long superstep_timeout_ms() {
+  if (const char* e = std::getenv("GRX_PARTITIONED_TIMEOUT_MS"))
+    return std::atoll(e);
+  return 30000;
+}
+
+/// A rank whose own step failed still takes part in the superstep's gather, with this in its
+/// slot's header word: every rank sees it in the same gather and returns an error.
+constexpr unsigned long long FAILED_HEAD = ~0ull;
+
+__global__ void mark_failed_kernel(int64_t* send) { send[0] = -1; }
+
+/// The ONE host wait of a superstep: spins on the sequence word the publish kernel stamps behind
+/// the gathered counts.  Bounded: a collective whose peer never arrives keeps the stream "not
+/// ready" for ever, so the wall clock decides.
 unsigned long long* await_heads(grx_partitioned_s& p, gcuda::standard_context_t& sc) {
   volatile unsigned long long* flag = p.heads->data() + (std::size_t)p.ctx->mc->world_size();
   unsigned spins = 0;
+  const long long limit_ms = superstep_timeout_ms();
+  const auto started = std::chrono::steady_clock::now();
   while (*flag < p.head_sequence) {
     __builtin_ia32_pause();
     if ((++spins & 0xFFFFu) == 0) {
       hipError_t st = hipStreamQuery(sc.stream());
       if (st != hipSuccess && st != hipErrorNotReady)
         error::throw_if_exception(st, "partitioned run: a superstep's kernels or collective failed");
+      if (limit_ms > 0 &&
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - started)
+                  .count() > limit_ms)
+        throw superstep_timeout_t("partitioned run: the gathered counts of a superstep did not arrive "
+                                  "within " + std::to_string(limit_ms) + " ms (a peer rank is gone or stuck)");
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -118,7 +155,7 @@ unsigned long long* await_heads(grx_partitioned_s& p, gcuda::standard_context_t&
 }
 
 template <typename label_t>
-int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* labels, label_t unreached,
+int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* caller_labels, label_t unreached,
            grx_partitioned_stats* stats) {
   auto& mc = *p.ctx->mc;
   auto& sc = p.ctx->single();
@@ -126,6 +163,13 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
   const int world = comm.world_size(), rank = comm.rank();
   hipStream_t stream = sc.stream();
   const unsigned grid = (unsigned)sc.compute_units() * 8;
+  // a slice of a renumbered copy: source in, labels out in the CALLER's numbering
+  static_assert(sizeof(label_t) == 4, "replicas hold 4-byte labels");
+  label_t* labels = caller_labels;
+  if (p.local->renumbered_slice) {
+    source = p.local->hot_rank_of[(std::size_t)source];
+    labels = reinterpret_cast<label_t*>(p.renumbered_labels.data());
+  }
 
   reset_run_kernel<label_t><<<grid, 256, 0, stream>>>(labels, p.stamp.data(), p.sent.data(), p.n,
                                                       unreached, source, p.lo, p.hi,
@@ -135,21 +179,56 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
   const auto traffic0 = comm.traffic();
   const auto t0 = std::chrono::steady_clock::now();
 
-  int rounds = 0, dense = 0, reduced = 0;
+  int rounds = 0, dense = 0, reduced = 0, large = 0;
   long long found_total = 0;
   const int64_t* recv_prev = nullptr;
   int64_t slot_prev = 0;
   int32_t fmt_prev = GRX_RECV_PAIRS;
   void* snapshot = edge_op == GRX_OP_SSSP ? (void*)p.snapshot.data() : nullptr;
+  // A failure on THIS rank (a buffer of its step overflowed, a kernel launch was refused, ...) must
+  // not leave the others inside a collective: the rank keeps taking part in the protocol without
+  // computing, announces the failure in its next send-slot header, and every rank leaves the loop
+  // in that same superstep with an error.
+  int failed = GRX_OK;
+  std::string why;
+  auto attempt = [&](auto&& body) {
+    if (failed != GRX_OK)
+      return;
+    try {
+      const int rc = body();
+      if (rc != GRX_OK) {
+        failed = rc;
+        why = last_error();
+      }
+    } catch (const superstep_timeout_t&) {
+      throw;
+    } catch (const std::exception& e) {
+      failed = GRX_ERR_RUNTIME;
+      why = e.what();
+    }
+  };
+  // test hook: GRX_PARTITIONED_FAIL_AT="<rank>:<superstep>" makes that rank's step fail there
+  int fail_rank = -1, fail_round = -1;
+  if (const char* e = std::getenv("GRX_PARTITIONED_FAIL_AT"))
+    std::sscanf(e, "%d:%d", &fail_rank, &fail_round);
+  p.ctx->superstep_finds_hint = -1;
   for (;;) {
-    int rc = grx_partitioned_step(p.ctx, p.local, &p.opts, edge_op, labels, p.stamp.data(),
+    attempt([&] {
+      if (rank == fail_rank && rounds == fail_round) {
+        last_error() = "injected failure (GRX_PARTITIONED_FAIL_AT)";
+        return (int)GRX_ERR_RUNTIME;
+      }
+      return grx_partitioned_step(p.ctx, p.local, &p.opts, edge_op, labels, p.stamp.data(),
                                   p.sent.data(), rounds, recv_prev, fmt_prev, world, slot_prev, rank,
                                   p.lo, p.hi, p.frontier.data(), (int64_t)p.frontier.size(),
                                   reinterpret_cast<uint64_t*>(p.fcount.data()), p.scratch.data(),
                                   (int64_t)p.scratch.size(), p.send.data(), (int64_t)p.send.size(),
                                   snapshot);
-    if (rc != GRX_OK)
-      return rc;
+    });
+    if (failed != GRX_OK) {
+      mark_failed_kernel<<<1, 1, 0, stream>>>(p.send.data());
+      GRX_HIP_CHECK(hipGetLastError());
+    }
     // every rank's [count | first pairs] -> every rank, on the stream that packed them
     comm.all_gather(p.send.data(), p.recv.data(), (std::size_t)p.slot0 * 8, stream);
     publish_heads_kernel<<<1, 64 * ((world + 63) / 64), 0, stream>>>(p.recv.data(), p.slot0, world,
@@ -158,9 +237,26 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
     GRX_HIP_CHECK(hipGetLastError());
     const unsigned long long* counts = await_heads(p, sc);  // the ONE host wait of the superstep
     long long most = 0, sum = 0;
+    int failed_peer = -1;
     for (int r = 0; r < world; ++r) {
+      if (counts[r] == FAILED_HEAD) {
+        failed_peer = failed_peer < 0 ? r : failed_peer;
+        continue;
+      }
       most = std::max<long long>(most, (long long)counts[r]);
       sum += (long long)counts[r];
+    }
+    if (failed_peer >= 0) {  // the same verdict on every rank, from the same gather
+      sc.synchronize();
+      p.ctx->pending_sequence = 0;
+      if (failed != GRX_OK) {
+        last_error() = "partitioned run: superstep " + std::to_string(rounds) + " failed on this rank (" +
+                       std::to_string(rank) + "): " + why;
+        return failed;
+      }
+      last_error() = "partitioned run: superstep " + std::to_string(rounds) + " failed on rank " +
+                     std::to_string(failed_peer) + "; this rank (" + std::to_string(rank) + ") stops with it";
+      return (int)GRX_ERR_PEER;
     }
     if (most == 0)
       break;  // no rank improved anything: every replica is final
@@ -170,10 +266,10 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
     int32_t fmt = GRX_RECV_PAIRS;
     if (edge_op == GRX_OP_BFS && p.dense_threshold >= 0 && most > p.dense_threshold) {
       // dense level: V/8 bytes per rank instead of 8 bytes per discovery
-      rc = grx_partitioned_level_bitmap(p.ctx, (const int32_t*)labels, p.n, rounds + 1,
-                                        p.bits.data(), (int64_t)p.bits.size());
-      if (rc != GRX_OK)
-        return rc;
+      attempt([&] {
+        return grx_partitioned_level_bitmap(p.ctx, (const int32_t*)labels, p.n, rounds + 1,
+                                            p.bits.data(), (int64_t)p.bits.size());
+      });
       comm.all_gather(p.bits.data(), p.recv_bits.data(), (std::size_t)p.words * 8, stream);
       recv = p.recv_bits.data();
       slot = p.words;
@@ -189,17 +285,25 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
       fmt = GRX_RECV_REPLICA_MIN;
       ++reduced;
     } else if (most > p.slot0 - 1) {
+      // recv_big was sized for the largest slot when the plan was made: nothing can fail here
       slot = std::min<int64_t>(((most + 1 + 4095) / 4096) * 4096, (int64_t)p.send.size());
-      if ((int64_t)p.recv_big.size() < (int64_t)world * slot)
-        p.recv_big.resize((std::size_t)((int64_t)world * slot));
       comm.all_gather(p.send.data(), p.recv_big.data(), (std::size_t)slot * 8, stream);
       recv = p.recv_big.data();
+      ++large;
     }
     found_total += sum;
+    p.ctx->superstep_finds_hint = sum;  // what the next step's owned frontiers add up to, at most
     recv_prev = recv;
     slot_prev = slot;
     fmt_prev = fmt;
     ++rounds;
+  }
+  p.ctx->superstep_finds_hint = -1;
+  if (p.local->renumbered_slice) {  // inside the timed run, like finalize() of the single-GPU clients
+    deliver_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const int32_t*>(labels),
+                                             p.local->hot_vertex_of.data(), p.n,
+                                             reinterpret_cast<int32_t*>(caller_labels));
+    GRX_HIP_CHECK(hipGetLastError());
   }
   sc.synchronize();
   const auto t1 = std::chrono::steady_clock::now();
@@ -220,6 +324,7 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* label
     stats->bytes_sent = (int64_t)(tr.bytes_sent - traffic0.bytes_sent);
     stats->bitmap_supersteps = dense;
     stats->allreduce_supersteps = reduced;
+    stats->large_gather_supersteps = large;
     stats->pairs_exchanged = found_total;
   }
   return (int)GRX_OK;
@@ -345,9 +450,15 @@ int grx_partitioned_create(grx_context_t ctx, grx_graph_t local, int32_t row_beg
     p->fcount.zero();
     p->recv.resize((std::size_t)((int64_t)world * p->slot0));
     p->recv.zero();
+    // the second, larger pair gather of a superstep takes at most a whole send buffer per rank:
+    // sized here so that the loop never allocates (an allocation failing on ONE rank in the middle
+    // of a superstep would leave the others inside the collective)
+    p->recv_big.resize((std::size_t)((int64_t)world * (int64_t)p->send.size()));
     p->bits.resize((std::size_t)p->words);
     p->recv_bits.resize((std::size_t)((int64_t)world * p->words));
     p->snapshot.resize((std::size_t)n);
+    if (local->renumbered_slice)
+      p->renumbered_labels.resize((std::size_t)n);
     p->heads = std::make_unique<hip::pinned_t<unsigned long long>>((std::size_t)world + 1);
     GRX_HIP_CHECK(hipDeviceSynchronize());
     *out = p.release();
@@ -375,9 +486,14 @@ int grx_partitioned_run(grx_partitioned_t plan, int32_t edge_op, int32_t source,
   if (plan->ctx->mc->world_size() * plan->slot0 != (int64_t)plan->recv.size())
     return invalid("grx_partitioned_run: the context's job changed since the plan was created");
   return guarded([&] {
-    if (edge_op == GRX_OP_BFS)
-      return run_as<int32_t>(*plan, edge_op, source, (int32_t*)d_labels, INT32_MAX, stats);
-    return run_as<float>(*plan, edge_op, source, (float*)d_labels, FLT_MAX, stats);
+    try {
+      if (edge_op == GRX_OP_BFS)
+        return run_as<int32_t>(*plan, edge_op, source, (int32_t*)d_labels, INT32_MAX, stats);
+      return run_as<float>(*plan, edge_op, source, (float*)d_labels, FLT_MAX, stats);
+    } catch (const superstep_timeout_t& e) {
+      last_error() = e.what();
+      return (int)GRX_ERR_TIMEOUT;
+    }
   });
 }
 
@@ -393,6 +509,11 @@ int grx_partitioned_pagerank(grx_partitioned_t plan, float alpha, float tol, int
     const std::size_t n = (std::size_t)p.n;
     p.scale.resize(n);
     p.partial.resize(n + 1);
+    // a slice of a renumbered copy: the iterations run on a renumbered vector, the caller's is
+    // written once at the end (ranks are per vertex: the numbering does not change them)
+    float* const caller_p = d_p;
+    if (p.local->renumbered_slice)
+      d_p = reinterpret_cast<float*>(p.renumbered_labels.data());
     hip::fill(d_p, n, 1.0f / (float)n, stream);
     sc.synchronize();
     const auto traffic0 = comm.traffic();
@@ -420,6 +541,12 @@ int grx_partitioned_pagerank(grx_partitioned_t plan, float alpha, float tol, int
       ++it;
       if (err < tol || (max_iterations && it >= max_iterations))
         break;
+    }
+    if (p.local->renumbered_slice) {
+      deliver_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const int32_t*>(d_p),
+                                               p.local->hot_vertex_of.data(), (int64_t)n,
+                                               reinterpret_cast<int32_t*>(caller_p));
+      GRX_HIP_CHECK(hipGetLastError());
     }
     sc.synchronize();
     const auto t1 = std::chrono::steady_clock::now();

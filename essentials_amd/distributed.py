@@ -668,12 +668,22 @@ class PartitionedRunner:
         self._deg = np.diff(ap).astype(np.int64)
         h = ea._VP()
         lo, hi = C.c_int32(), C.c_int32()
-        ea._check(ea.load_library().grx_graph_partition(full._h, self.rank, self.world, C.byref(h),
-                                                        C.byref(lo), C.byref(hi)),
-                  "grx_graph_partition")
+        # the C++ superstep loop runs on slices of the graph's hot-first renumbered copy and hands
+        # the labels back in this graph's numbering (grx_graph_partition_hot_first); the
+        # torch.distributed loop drives single supersteps and keeps the plain slices
+        self.renumbered = exchange in ("rccl", "hooks") and os.environ.get("GRX_HOT_FIRST", "1") != "0"
+        if self.renumbered:
+            ea._check(ea.load_library().grx_graph_partition_hot_first(
+                ctx._h, full._h, self.rank, self.world, C.byref(h), C.byref(lo), C.byref(hi)),
+                "grx_graph_partition_hot_first")
+        else:
+            ea._check(ea.load_library().grx_graph_partition(full._h, self.rank, self.world, C.byref(h),
+                                                            C.byref(lo), C.byref(hi)),
+                      "grx_graph_partition")
         self.local = ea.Graph(h)
         self.lo, self.hi = lo.value, hi.value
-        assert [self.lo, self.hi] == partition_bounds(ap, self.world)[self.rank:self.rank + 2]
+        if not self.renumbered:
+            assert [self.lo, self.hi] == partition_bounds(ap, self.world)[self.rank:self.rank + 2]
         full.close()
         dev = f"cuda:{ctx.device}"
         self.depth = torch.empty(self.n, dtype=torch.int32, device=dev)
@@ -701,6 +711,17 @@ class PartitionedRunner:
                     pass
                 self.exchange_note = f"'{exchange}' attachment failed on some rank ({why}); torch.distributed loop"
                 self.exchange = exchange = "torch"
+                if self.renumbered:   # that loop drives single supersteps: plain slices, caller's ids
+                    self.local.close()
+                    full = ea.Graph.rmat(ctx, scale, edge_factor, seed, weight_seed, True)
+                    h = ea._VP()
+                    ea._check(ea.load_library().grx_graph_partition(full._h, self.rank, self.world, C.byref(h),
+                                                                    C.byref(lo), C.byref(hi)),
+                              "grx_graph_partition")
+                    self.local = ea.Graph(h)
+                    self.lo, self.hi = lo.value, hi.value
+                    self.renumbered = False
+                    full.close()
         if exchange == "torch":
             fused = options is None or options.load_balance == ea.LoadBalance.block_mapped
             with torch.cuda.stream(self.stream):

@@ -37,7 +37,13 @@ typedef enum grx_status {
   GRX_OK = 0,
   GRX_ERR_INVALID_ARGUMENT = -1,
   GRX_ERR_RUNTIME = -2,      /* HIP / RCCL failure or an engine exception */
-  GRX_ERR_UNSUPPORTED = -3   /* variant not implemented (reference: "... not supported") */
+  GRX_ERR_UNSUPPORTED = -3,  /* variant not implemented (reference: "... not supported") */
+  GRX_ERR_PEER = -4,         /* partitioned run: ANOTHER rank's superstep failed; every rank of the
+                                job returns an error from the same superstep (the failing rank its own) */
+  GRX_ERR_TIMEOUT = -5       /* partitioned run: the gathered counts of a superstep did not arrive
+                                within GRX_PARTITIONED_TIMEOUT_MS (default 30 s) -- a peer is gone or
+                                stuck.  The stream still holds the unfinished collective: the caller
+                                should exit (not re-exec) without synchronising this context. */
 } grx_status;
 
 /* operators::load_balance_t (reference framework/operators/configs.hxx:31-39), same order */
@@ -268,6 +274,16 @@ int grx_uniquify(grx_context_t ctx, int32_t algorithm, int32_t best_effort, int3
 /* Rank-local slice of a replicated graph; split points balance EDGES (prefix of row offsets). */
 int grx_graph_partition(grx_graph_t full, int rank, int world_size, grx_graph_t* out,
                         int32_t* row_begin, int32_t* row_end);
+/* The same slice of the graph's HOT-FIRST renumbered copy (grx_graph_hot_first; built here if the
+ * handle has none yet): [row_begin, row_end) is then a range of RENUMBERED vertices (edge-balanced
+ * like above: the first ranks own few, heavy vertices), and the slice remembers both permutations.
+ * grx_partitioned_run on a plan made from it takes the source and delivers the labels in the
+ * CALLER's numbering (sources in, labels out, as for grx_bfs): the supersteps run on renumbered
+ * replicas, one scatter pass at the end of the run writes d_labels.  The single-superstep entry
+ * points below (grx_partitioned_expand / _admit / _step) see such a slice as the plain graph it is --
+ * renumbered ids in and out. */
+int grx_graph_partition_hot_first(grx_context_t ctx, grx_graph_t full, int rank, int world_size,
+                                  grx_graph_t* out, int32_t* row_begin, int32_t* row_end);
 /* d_labels: replica [V] (int32 depth for GRX_OP_BFS, float distance for GRX_OP_SSSP).
  * round: superstep number (the BFS level).  d_frontier / n_frontier: owned input frontier
  * (global ids).  d_scratch: int32[scratch_capacity] workspace for the raw output frontier
@@ -385,6 +401,10 @@ typedef struct grx_partitioned_stats {
   float last_error;             /* PageRank: max |p - p_previous| of the last iteration          */
   int64_t pairs_exchanged;      /* finds of all ranks over the run                               */
   int64_t bytes_sent;           /* payload bytes this rank contributed to collectives            */
+  int32_t large_gather_supersteps; /* supersteps whose pairs outgrew the first (small) slot: one
+                                      more all-gather; collectives == supersteps + bitmap_ +
+                                      allreduce_ + large_gather_supersteps for a traversal        */
+  int32_t reserved;
 } grx_partitioned_stats;
 int grx_partitioned_create(grx_context_t ctx, grx_graph_t local, int32_t row_begin, int32_t row_end,
                            const grx_options* opt, int64_t small_slot, int64_t dense_threshold,

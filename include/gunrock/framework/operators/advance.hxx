@@ -375,7 +375,8 @@ void execute(graph_t& G,
             fit.allowed = cu_lds - fit.static_bytes;
           }
           kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
-              G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors);
+              G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors,
+              (const unsigned long long*)nullptr);
           GRX_HIP_CHECK(hipGetLastError());
           expanded = true;
         }
@@ -464,6 +465,59 @@ void enqueue_packed(graph_t& G,
                            k::ADV_BLOCK, 0, context.stream()>>>(G, op, chunks, chunk_capacity, output,
                                                                 capacity, counters);
   GRX_HIP_CHECK(hipGetLastError());
+}
+
+/**
+ * @brief enqueue_packed for a WIDE frontier of a client that named its settled destinations
+ * (operators/settled.hxx): hub pre-pass + expand_settled_kernel, frontier length read on the device,
+ * nothing fetched, nothing awaited.  Returns false (nothing enqueued) when the kernel's LDS image
+ * does not fit this device: the caller falls back to enqueue_packed.
+ */
+template <typename graph_t, typename operator_t, typename vertex_t>
+bool enqueue_packed_settled(graph_t& G,
+                            operator_t op,
+                            const vertex_t* input,
+                            std::size_t n_in_bound,
+                            const unsigned long long* n_in_device,
+                            unsigned long long work_bound,
+                            vertex_t* output,
+                            std::size_t capacity,
+                            gcuda::standard_context_t& context) {
+  namespace k = detail::k;
+  using edge_t = typename graph_t::edge_type;
+  constexpr advance_io_type_t vin = advance_io_type_t::vertices;
+  static_assert(settled_traits<operator_t>::value, "enqueue_packed_settled takes a hinted functor");
+  if (n_in_bound == 0)
+    return true;
+  auto kernel = k::expand_settled_kernel<vin, vin, graph_t, operator_t, vertex_t, edge_t>;
+  if (!op.settled.bits)
+    op.settled.limit = 0;
+  const std::size_t lds = op.settled.limit > 0 ? op.lds_bytes() : 16;
+  hipFuncAttributes fa;
+  GRX_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)));
+  const std::size_t cu_lds = 160u << 10;
+  if (fa.sharedSizeBytes + lds > cu_lds)
+    return false;
+  GRX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(cu_lds - fa.sharedSizeBytes)));
+  (void)detail::max_degree(G, context);
+  unsigned long long chunk_capacity = 0;
+  auto* chunks = detail::chunk_queue<vertex_t, edge_t>(G, n_in_bound, work_bound, chunk_capacity, context);
+  const unsigned hub_threshold = context.options().hub_threshold;
+  const unsigned chunk_edges = context.options().chunk_edges ? context.options().chunk_edges : 1024u;
+  unsigned long long* counters = context.workspace().counters();
+  auto* cursors = reinterpret_cast<unsigned long long*>(context.workspace().scratch(
+      (8 * k::CLAIM_LINE + (n_in_bound + 63) / 64) * sizeof(unsigned long long)));
+  auto* mask = cursors + 8 * k::CLAIM_LINE;
+  k::classify_hubs_kernel<vin>
+      <<<detail::grid_for(n_in_bound, k::CLASSIFY_TILE, (unsigned)context.compute_units() * 8u), k::ADV_BLOCK, 0,
+         context.stream()>>>(G, input, n_in_bound, n_in_device, chunks, chunk_capacity, hub_threshold,
+                             chunk_edges, mask, cursors, counters);
+  kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
+      G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, mask, cursors, n_in_device);
+  GRX_HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 }  // namespace block_mapped

@@ -78,6 +78,10 @@ struct exchange_state_t {
 /// every rank, only its owner starts from it.
 template <typename frontier_t>
 void keep_owned(frontier_t& f, gcuda::multi_context_t& context) {
+  // a client may have pushed its source with the STREAMED push_back (a fill kernel on the
+  // context's non-blocking stream, nothing awaited): to_host() copies on the null stream, which
+  // is not ordered after it
+  context.get_context(0)->synchronize();
   auto h = f.to_host();
   std::vector<typename frontier_t::type_t> mine;
   for (auto v : h)

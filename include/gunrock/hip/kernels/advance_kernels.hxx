@@ -826,10 +826,13 @@ __global__ void __launch_bounds__(SET_BLOCK)
                           const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
                           unsigned long long chunk_capacity,
                           const unsigned long long* __restrict__ hub_mask,
-                          unsigned long long* __restrict__ claim_cursors) {
+                          unsigned long long* __restrict__ claim_cursors,
+                          const unsigned long long* n_in_device = nullptr) {
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   using weight_t = typename graph_t::weight_type;
   using pending_t = pending_edge_t<vertex_t, edge_t>;
+  if (n_in_device)  // fused pipelines: the frontier length was written by a kernel earlier in the stream
+    n_in = (std::size_t)__hip_atomic_load(n_in_device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   extern __shared__ unsigned s_settled[];  // op.settled.limit bits
   __shared__ vertex_t s_vertex[SET_BLOCK];
   __shared__ edge_t s_first[SET_BLOCK];

@@ -210,7 +210,70 @@ def _rank(rank, world, port, scale, out_dir):
                 notes.append(f"c++ loop sssp {s} {small_slot} {replica}")
             if dense == 32 and not (st1["bitmap_supersteps"] and st2["allreduce_supersteps"]):
                 notes.append(f"c++ loop: dense exchanges not taken {st1} {st2}")
+            # the protocol, pinned: ONE gather of the send slots per superstep, plus one more
+            # collective in the supersteps that exchanged a level bitmap / all-reduced the replicas /
+            # needed the larger pair gather -- a regression that doubles the exchanges fails here.
+            # Supersteps: one per BFS level (the last one finds nothing) -- the oracle's eccentricity.
+            n = full.n_rows
+            slot0 = max(2, min(small_slot if small_slot > 0 else 1 << 15, n + 2))
+            words = (n + 63) // 64
+            for name, st, extra in (("bfs", st1, 8 * words * st1["bitmap_supersteps"]),
+                                    ("sssp", st2, 4 * n * st2["allreduce_supersteps"])):
+                want_coll = (st["supersteps"] + st["bitmap_supersteps"] + st["allreduce_supersteps"]
+                             + st["large_gather_supersteps"])
+                if st["collectives"] != want_coll:
+                    notes.append(f"c++ loop {name} {s}: {st['collectives']} collectives, protocol says {want_coll} {st}")
+                if st["large_gather_supersteps"] == 0 and st["bytes_sent"] != 8 * slot0 * st["supersteps"] + extra:
+                    notes.append(f"c++ loop {name} {s}: bytes_sent {st['bytes_sent']} {st}")
+            if st1["supersteps"] != int(want[want != 2**31 - 1].max()) + 1:
+                notes.append(f"c++ loop bfs {s}: {st1['supersteps']} supersteps for eccentricity {want[want != 2**31 - 1].max()}")
+            if (small_slot, dense) == (64, -1) and not st1["large_gather_supersteps"]:
+                notes.append(f"c++ loop bfs {s}: a 64-word slot must have needed the larger gather {st1}")
+            if small_slot == 0 and (st1["bitmap_supersteps"] or st1["large_gather_supersteps"] or
+                                    st2["allreduce_supersteps"] or st2["large_gather_supersteps"]):
+                notes.append(f"c++ loop {s}: default slots of a 4 K-vertex graph need one gather per superstep {st1} {st2}")
         plan.close()
+    # slices of the HOT-FIRST renumbered copy (grx_graph_partition_hot_first): sources in, labels out
+    # in the caller's numbering, whatever the replicas are numbered like inside
+    h2, lo2, hi2 = api._VP(), C.c_int32(), C.c_int32()
+    api._check(api.load_library().grx_graph_partition_hot_first(cctx._h, full._h, rank, world, C.byref(h2),
+                                                                C.byref(lo2), C.byref(hi2)), "partition hot-first")
+    local2 = ea.Graph(h2)
+    if local2.nnz > 0 and rank > 0 and not lo2.value > 0:
+        notes.append("hot-first partition: rank > 0 must start behind the heavy vertices")
+    for small_slot, dense, replica in ((0, 0, 0), (64, 32, 32)):
+        plan = ea.PartitionedPlan(cctx, local2, lo2.value, hi2.value, None, small_slot, dense, replica)
+        for s in (0, 1830):
+            depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+            plan.run(ea.EdgeOp.bfs, s, depth)
+            if not (depth.cpu().numpy() == o.bfs_heap(Ap, Aj, s)[0]).all():
+                notes.append(f"renumbered slices: bfs {s} {small_slot}")
+            d = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+            plan.run(ea.EdgeOp.sssp, s, d)
+            if not (d.cpu().numpy().view(np.uint32) == o.sssp_heap(Ap, Aj, Ax, s)[0].view(np.uint32)).all():
+                notes.append(f"renumbered slices: sssp {s} {small_slot}")
+        p2 = torch.empty(full.n_rows, dtype=torch.float32, device="cuda")
+        plan.pagerank(p2, 0.85, 1e-6)
+        if not np.allclose(p2.cpu().numpy(), o.pagerank(Ap, Aj, Ax, 0.85, 1e-6)[0], rtol=2e-4, atol=1e-9):
+            notes.append("renumbered slices: pagerank")
+        plan.close()
+    # a failure on ONE rank (injected: rank 1's step of superstep 2 fails) ends the run on EVERY rank,
+    # in the same superstep, with an error -- nobody is left inside a collective; the plan works again
+    plan = ea.PartitionedPlan(cctx, local, lo.value, hi.value, None, 64, -1, -1)
+    os.environ["GRX_PARTITIONED_FAIL_AT"] = "1:2"
+    depth = torch.empty(full.n_rows, dtype=torch.int32, device="cuda")
+    try:
+        plan.run(ea.EdgeOp.bfs, 0, depth)
+        notes.append("injected failure: the run returned normally")
+    except api.EngineError as e:
+        want_code = -2 if rank == 1 else api.ERR_PEER
+        if e.code != want_code or "superstep 2" not in str(e):
+            notes.append(f"injected failure: rank {rank} got {e.code}: {e}")
+    del os.environ["GRX_PARTITIONED_FAIL_AT"]
+    plan.run(ea.EdgeOp.bfs, 0, depth)
+    if not (depth.cpu().numpy() == o.bfs_heap(Ap, Aj, 0)[0]).all():
+        notes.append("the plan does not work after a failed run")
+    plan.close()
     # the REFERENCE's unchanged bfs.hxx / sssp.hxx as ranks of this job (oracle/_ref, when built):
     # enactor_t::enact() exchanges the frontiers, the client headers are not touched
     from oracle.oracle import RefClients
@@ -283,6 +346,13 @@ def _rank_large(rank, world, port, scale, out_dir):
     local = ea.Graph(h)
     attach_job(ctx, dist)
     plan = ea.PartitionedPlan(ctx, local, lo.value, hi.value)
+    # and the form bench.py uses: slices of the hot-first renumbered copy (wide BFS supersteps then
+    # run the settled-bitmap kernel on the heavy low ids)
+    h2, lo2, hi2 = api._VP(), C.c_int32(), C.c_int32()
+    api._check(api.load_library().grx_graph_partition_hot_first(ctx._h, full._h, rank, world, C.byref(h2),
+                                                                C.byref(lo2), C.byref(hi2)), "partition hot-first")
+    local2 = ea.Graph(h2)
+    plan2 = ea.PartitionedPlan(ctx, local2, lo2.value, hi2.value)
     notes = []
     single = ea.Context(0)
     for s in (0, 12345):
@@ -296,6 +366,14 @@ def _rank_large(rank, world, port, scale, out_dir):
             notes.append(f"bfs {s}: {int((depth != want_d).sum())} depths differ {st}")
         if not torch.equal(w.view(torch.int32), want_w.view(torch.int32)):
             notes.append(f"sssp {s}: distances differ {st2}")
+        depth.fill_(-7)
+        w.fill_(-7.0)
+        st3 = plan2.run(ea.EdgeOp.bfs, s, depth)
+        st4 = plan2.run(ea.EdgeOp.sssp, s, w)
+        if not torch.equal(depth, want_d) or not torch.equal(w.view(torch.int32), want_w.view(torch.int32)):
+            notes.append(f"renumbered slices, source {s}: labels differ {st3} {st4}")
+        if st3["supersteps"] != st["supersteps"]:
+            notes.append(f"renumbered slices, source {s}: {st3['supersteps']} BFS supersteps, plain slices {st['supersteps']}")
         if rank == 0:
             print(f"scale {scale} x{world} source {s}: bfs {st['supersteps']} supersteps "
                   f"({st['bitmap_supersteps']} bitmap) {st['elapsed_ms']:.1f} ms; sssp "
