@@ -125,6 +125,13 @@ grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
   h->max_degree_known = true;
   h->symmetry = g->symmetry;  // renumbering keeps (a)symmetry
   h->hot_first = 0;           // a copy has no copy of its own
+  {  // descending degree order: the vertices with edges come first -- how many are there?
+    const int32_t* hap = h->d_ap;
+    h->leading_connected = hip::transform_reduce(
+        (std::size_t)g->n_rows,
+        [hap] __device__(std::size_t i) -> unsigned long long { return hap[i + 1] > hap[i] ? 1ull : 0ull; },
+        0ull, rocprim::plus<unsigned long long>(), ctx->single());
+  }
   g->hot_rank_of.resize((std::size_t)g->n_rows);
   GRX_HIP_CHECK(hipMemcpy(g->hot_rank_of.data(), R.rank_of.data(), (std::size_t)g->n_rows * 4,
                           hipMemcpyDeviceToHost));

@@ -122,6 +122,8 @@ struct grx_graph_s {
   // this handle IS a slice of a renumbered copy (grx_graph_partition_hot_first): the two arrays
   // above are the permutations grx_partitioned_run translates with
   bool renumbered_slice = false;
+  // a renumbered copy: its vertices with edges come first, this many of them (0 = not such a copy)
+  unsigned long long leading_connected = 0;
 
   essentials_amd::graph_type view() const {
     using namespace gunrock;
@@ -135,6 +137,7 @@ struct grx_graph_s {
     // never 0 ("unknown"): an edgeless graph reports 1, which only loosens a sizing bound
     G.properties.max_degree = max_degree ? max_degree : 1ull;
     G.properties.symmetric = symmetry == symmetric;
+    G.properties.leading_connected = leading_connected;
     if (in_edges) {
       G.properties.directed = true;
       in_edges->attach_to(G);

@@ -172,9 +172,10 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
 
   void finalize(gcuda::multi_context_t&) override { this->get_problem()->deliver(); }
 
-  /// One level.  `visit` discovers, `has_depth` is its pure "already discovered" test.
-  template <typename visit_t, typename has_depth_t>
-  void expand(visit_t visit, has_depth_t has_depth, gcuda::multi_context_t& context) {
+  /// One level.  `visit` discovers, `has_depth` is its pure "already discovered" test,
+  /// `found_now(v)` says that THIS level discovered v (asked after the level).
+  template <typename visit_t, typename has_depth_t, typename found_t>
+  void expand(visit_t visit, has_depth_t has_depth, found_t found_now, gcuda::multi_context_t& context) {
     auto E = this->get_enactor();
     auto G = this->get_problem()->get_graph();
     // wide levels (block_mapped's fused form): every vertex that has a depth is settled -- visit()
@@ -189,6 +190,22 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         operators::advance::detail::clocked_t clock(*ctx);
         settled.rebuild((std::size_t)G.get_number_of_vertices(), has_depth, *ctx);
         clock.stop();
+      }
+      if (ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work) {
+        // the widest levels: no output frontier at all -- the labels say what the level found, and
+        // one pass over them builds the next frontier in ascending runs with its degree sum
+        // (operators::filter::select_range; the graph's vertices without edges are skipped when a
+        // hot-first numbering put them last)
+        operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                    operators::advance_io_type_t::vertices,
+                                    operators::advance_io_type_t::none>(
+            G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+        const std::size_t n_scan = G.properties.leading_connected
+                                       ? (std::size_t)G.properties.leading_connected
+                                       : (std::size_t)G.get_number_of_vertices();
+        operators::filter::select_range(G, n_scan, found_now, *E->get_output_frontier(), *ctx);
+        E->swap_frontier_buffers();
+        return;
       }
       operators::advance::execute<lb>(
           G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
@@ -225,7 +242,10 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
       auto has_byte = [words] __device__(vertex_t const& v) -> bool {
         return ((words[(unsigned)v >> 2] >> (((unsigned)v & 3u) * 8u)) & 0xFFu) != 0xFFu;
       };
-      expand(visit_byte, has_byte, context);
+      auto found_byte = [words, level] __device__(vertex_t const& v) -> bool {
+        return ((words[(unsigned)v >> 2] >> (((unsigned)v & 3u) * 8u)) & 0xFFu) == level;
+      };
+      expand(visit_byte, has_byte, found_byte, context);
       return;
     }
     auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
@@ -239,7 +259,10 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     auto has_depth = [depth] __device__(vertex_t const& v) -> bool {
       return depth[v] != std::numeric_limits<vertex_t>::max();
     };
-    expand(visit, has_depth, context);
+    auto found_now = [depth, next_level] __device__(vertex_t const& v) -> bool {
+      return depth[v] == next_level;
+    };
+    expand(visit, has_depth, found_now, context);
   }
   operators::advance::settled_filter_t<vertex_t> settled;
 };
@@ -525,6 +548,21 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
 
   void finalize(gcuda::multi_context_t&) override { this->get_problem()->unpack(); }
 
+  /// The next frontier of a round that ran without an output frontier: the vertices whose packed
+  /// label carries this round's tag (operators::filter::select_range), then swap.
+  void scan_improved(const unsigned long long* packed, unsigned this_round, gcuda::multi_context_t& context) {
+    auto E = this->get_enactor();
+    auto G = this->get_problem()->get_graph();
+    auto ctx = context.get_context(0);
+    const std::size_t n_scan = G.properties.leading_connected ? (std::size_t)G.properties.leading_connected
+                                                              : (std::size_t)G.get_number_of_vertices();
+    auto lowered_now = [packed, this_round] __device__(vertex_t const& v) -> bool {
+      return (unsigned)packed[v] == this_round;
+    };
+    operators::filter::select_range(G, n_scan, lowered_now, *E->get_output_frontier(), *ctx);
+    E->swap_frontier_buffers();
+  }
+
   void loop(gcuda::multi_context_t& context) override {
     auto E = this->get_enactor();
     auto P = this->get_problem();
@@ -649,11 +687,30 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
                                                           edge_t const& edge, weight_t const& w) -> bool {
             return cached(src, dst, edge, w, bound16[dst]);
           };
-          operators::advance::execute<lb>(
-              G, E,
-              operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter, cached, bound16,
-                                                        (std::size_t)G.get_number_of_vertices()),
-              context);
+          auto hinted = operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter, cached, bound16,
+                                                                  (std::size_t)G.get_number_of_vertices());
+          if (ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work) {
+            // no output frontier: the round tag in a label's low word says "lowered in this round"
+            operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                        operators::advance_io_type_t::vertices,
+                                        operators::advance_io_type_t::none>(G, E, hinted, context);
+            scan_improved(packed, this_round, context);
+            return;
+          }
+          operators::advance::execute<lb>(G, E, hinted, context);
+          return;
+        }
+      }
+      {
+        auto ctx = context.get_context(0);
+        const unsigned long long work = E->get_input_frontier()->work_hint();
+        if (lb == load_balance_t::block_mapped && !ctx->options().holes_layout &&
+            ctx->options().label_scan_min_work && work != frontier_t::unknown_work &&
+            work >= ctx->options().label_scan_min_work) {
+          operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::vertices,
+                                      operators::advance_io_type_t::none>(G, E, relax_packed, context);
+          scan_improved(packed, this_round, context);
           return;
         }
       }

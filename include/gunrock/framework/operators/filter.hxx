@@ -18,6 +18,7 @@
  */
 #pragma once
 
+#include <gunrock/framework/operators/advance.hxx>
 #include <gunrock/framework/operators/configs.hxx>
 #include <gunrock/hip/context.hxx>
 #include <gunrock/hip/kernels/advance_kernels.hxx>
@@ -131,6 +132,46 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output,
   compact::execute(G, op, input, output, context);
 }
 }  // namespace remove
+
+/**
+ * @brief output <- the vertices v in [0, n) with pred(v), and output's work hint <- the sum of their
+ * degrees: what `output.sequence(0, n)` followed by filter::execute<predicated>(G, pred, ...) yields
+ * as a SET (reference frontier.hxx sequence + filter/predicated.hxx:24-38), in one pass and with
+ * ids ascending inside every run of 8192 candidates (compact_kernels.hxx: select_range_kernel).
+ * The engine extension behind "run a wide level without an output frontier, then name what it found".
+ * pred is called exactly once per v, in no particular order.  Synchronous.
+ */
+template <typename graph_t, typename pred_t, typename frontier_t>
+void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
+                  gcuda::standard_context_t& context) {
+  namespace k = ::gunrock::hip::kernels;
+  using vertex_t = typename frontier_t::type_t;
+  if (n == 0) {
+    output.set_number_of_elements(0);
+    output.set_work_hint(0);
+    return;
+  }
+  if (output.get_capacity() < 64)
+    output.reserve(64);
+  const std::size_t chunks = (n + k::SEL_CHUNK - 1) / k::SEL_CHUNK;
+  const std::size_t cap = (std::size_t)context.compute_units() * 2;
+  operators::advance::detail::clocked_t clock(context);  // it IS a level's output path: timed with the advances
+  k::select_range_kernel<vertex_t><<<(unsigned)(chunks < cap ? chunks : cap), k::SEL_BLOCK, 0,
+                                     context.stream()>>>(G, n, pred, output.data(), output.get_capacity(),
+                                                         context.workspace().counters(), (int)k::C_OUT,
+                                                         (int)k::C_NEXT_WORK, (int)k::C_OVERFLOW);
+  GRX_HIP_CHECK(hipGetLastError());
+  clock.stop();
+  unsigned long long* m = operators::advance::detail::fetch_counters(context);
+  context.kernel_clock().collect();
+  if (m[k::C_OVERFLOW] != 0) {  // more matches than the frontier holds: grow and repeat (pred is pure here)
+    output.reserve((std::size_t)m[k::C_OUT]);
+    select_range(G, n, pred, output, context);
+    return;
+  }
+  output.set_number_of_elements((std::size_t)m[k::C_OUT]);
+  output.set_work_hint(m[k::C_NEXT_WORK]);
+}
 
 /// Frontier-level entry (reference filter.hxx:59-86).
 template <filter_algorithm_t alg_type, typename graph_t, typename operator_t, typename frontier_t>

@@ -38,6 +38,10 @@ struct graph_properties_t {
   /// -- which cannot tell apart two graphs built one after the other in the same memory, so
   /// owners of long-lived graphs should set it (the C ABI's graph handles do).
   unsigned long long max_degree{0};
+  /// Hot-first renumbered graphs (graph/reorder.hxx): every vertex with an edge comes before every
+  /// vertex without one, and this many vertices have edges (0 = not known / not so ordered).  A pass
+  /// over "the vertices an edge can lead to" stops there.
+  unsigned long long leading_connected{0};
 };
 
 enum view_t : uint32_t { invalid = 1u << 0, csr = 1u << 1, csc = 1u << 2, coo = 1u << 3 };

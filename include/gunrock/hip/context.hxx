@@ -185,6 +185,11 @@ struct operator_options_t {
   bool settled_filter = true;
   /// ... from this many edges of work on (a level of a few hubs is as wide as one of 1 M slots).
   unsigned long long settled_min_work = 1ull << 20;
+  /// Clients that can name "what this level found" as a predicate of the vertex (BFS: depth ==
+  /// level) run a level of at least this many edges of work WITHOUT an output frontier and build the
+  /// next one by one pass over the labels (operators::filter::select_range: sorted runs, degree sum
+  /// for free); 0 = never.  Below it the advance packs its output as before.
+  unsigned long long label_scan_min_work = 16ull << 20;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -296,6 +301,8 @@ class standard_context_t {
       options_.settled_filter = std::atoi(e) != 0;
     if (const char* e = std::getenv("GRX_SETTLED_MIN_WORK"))
       options_.settled_min_work = (unsigned long long)std::atoll(e);
+    if (const char* e = std::getenv("GRX_LABEL_SCAN_MIN_WORK"))
+      options_.label_scan_min_work = (unsigned long long)std::atoll(e);
     if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))
       options_.chunk_queue_limit = (unsigned long long)std::atoll(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));

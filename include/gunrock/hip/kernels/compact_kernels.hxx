@@ -117,6 +117,83 @@ __global__ void __launch_bounds__(CMP_BLOCK)
   }
 }
 
+// ---------------------------------------------------------------------------
+// select_range: the ids i in [0, n) with pred(i), in ONE pass, as sorted runs.
+//
+// Why: a wide BFS / SSSP level spends 70-130 us of its 0.5-1.0 ms on its OUTPUT path (per-wavefront
+// LDS queues, degree look-ups of the emitted neighbours, ~10 K claims on the output cursor, scattered
+// 4-byte writes).  A client whose labels say what the level found (BFS: depth == level) can run the
+// level with output_type = none and call this instead: one coalesced pass over the labels (16 MB at
+// 2^22 vertices), one cursor claim per 8192 ids, the degree sum of the selection (the next
+// advance's work hint) from the row offsets it streams past anyway, and a frontier whose ids ascend
+// inside every run of one chunk.  Same result SET as sequence(0, n) + filter::predicated; the order
+// between chunks is the order in which workgroups claimed space.
+// ---------------------------------------------------------------------------
+constexpr int SEL_BLOCK = 1024;
+constexpr int SEL_ITEMS = 8;
+constexpr int SEL_CHUNK = SEL_BLOCK * SEL_ITEMS;  // 8192 ids per claim
+constexpr int SEL_WAVES = SEL_BLOCK / wave_size;  // 16
+
+template <typename vertex_t, typename graph_t, typename pred_t>
+__global__ void __launch_bounds__(SEL_BLOCK)
+    select_range_kernel(graph_t G, std::size_t n, pred_t pred, vertex_t* __restrict__ out,
+                        std::size_t capacity, unsigned long long* counters, int cursor_slot,
+                        int work_slot, int overflow_slot) {
+  __shared__ unsigned s_count[SEL_ITEMS * SEL_WAVES];   // matches per (k, wave), then their prefix
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned long long s_work[SEL_WAVES];
+  const int tid = threadIdx.x, lane = lane_id(), wave = tid / wave_size;
+  unsigned long long work = 0;
+  const std::size_t n_chunks = (n + SEL_CHUNK - 1) / SEL_CHUNK;
+  for (std::size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    unsigned long long mask[SEL_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SEL_ITEMS; ++k) {
+      const std::size_t i = chunk * SEL_CHUNK + (std::size_t)k * SEL_BLOCK + tid;
+      const bool keep = i < n && pred((vertex_t)i);
+      mask[k] = __ballot(keep);
+      if (keep)
+        work += (unsigned long long)G.get_number_of_neighbors((vertex_t)i);
+      if (lane == 0)
+        s_count[k * SEL_WAVES + wave] = (unsigned)__popcll(mask[k]);
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive prefix over the 128 (k, wave) groups, two per lane
+      const unsigned a = s_count[2 * lane], b = s_count[2 * lane + 1];
+      const unsigned incl = wave_inclusive_sum(a + b);
+      s_count[2 * lane] = incl - a - b;
+      s_count[2 * lane + 1] = incl - b;
+      if (lane == wave_size - 1)
+        s_base = incl ? atomicAdd(&counters[cursor_slot], (unsigned long long)incl) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+#pragma unroll
+    for (int k = 0; k < SEL_ITEMS; ++k) {
+      if ((mask[k] >> lane) & 1ull) {
+        const unsigned long long at = base + s_count[k * SEL_WAVES + wave] + rank_in_mask(mask[k]);
+        if (at < capacity)
+          out[at] = (vertex_t)(chunk * SEL_CHUNK + (std::size_t)k * SEL_BLOCK + tid);
+        else
+          counters[overflow_slot] = 1ull;
+      }
+    }
+    __syncthreads();  // s_count / s_base are rewritten by the next chunk
+  }
+  work = wave_sum(work);
+  if (lane == 0)
+    s_work[wave] = work;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_WAVES; ++w)
+      t += s_work[w];
+    if (t)
+      atomicAdd(&counters[work_slot], t);
+  }
+}
+
 /// Number of tiles for n elements.
 inline std::size_t compaction_tiles(std::size_t n) { return (n + CMP_TILE - 1) / CMP_TILE; }
 
