@@ -196,10 +196,12 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         // one pass over them builds the next frontier in ascending runs with its degree sum
         // (operators::filter::select_range; the graph's vertices without edges are skipped when a
         // hot-first numbering put them last)
+        ctx->options().defer_sync_of_none_output = true;  // select_range below is its hand-off
         operators::advance::execute<lb, operators::advance_direction_t::forward,
                                     operators::advance_io_type_t::vertices,
                                     operators::advance_io_type_t::none>(
             G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+        ctx->options().defer_sync_of_none_output = false;
         const std::size_t n_scan = G.properties.leading_connected
                                        ? (std::size_t)G.properties.leading_connected
                                        : (std::size_t)G.get_number_of_vertices();
@@ -691,9 +693,11 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
                                                                   (std::size_t)G.get_number_of_vertices());
           if (ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work) {
             // no output frontier: the round tag in a label's low word says "lowered in this round"
+            ctx->options().defer_sync_of_none_output = true;  // scan_improved below is its hand-off
             operators::advance::execute<lb, operators::advance_direction_t::forward,
                                         operators::advance_io_type_t::vertices,
                                         operators::advance_io_type_t::none>(G, E, hinted, context);
+            ctx->options().defer_sync_of_none_output = false;
             scan_improved(packed, this_round, context);
             return;
           }
@@ -707,9 +711,11 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
         if (lb == load_balance_t::block_mapped && !ctx->options().holes_layout &&
             ctx->options().label_scan_min_work && work != frontier_t::unknown_work &&
             work >= ctx->options().label_scan_min_work) {
+          ctx->options().defer_sync_of_none_output = true;  // scan_improved below is its hand-off
           operators::advance::execute<lb, operators::advance_direction_t::forward,
                                       operators::advance_io_type_t::vertices,
                                       operators::advance_io_type_t::none>(G, E, relax_packed, context);
+          ctx->options().defer_sync_of_none_output = false;
           scan_improved(packed, this_round, context);
           return;
         }

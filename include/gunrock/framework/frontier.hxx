@@ -93,7 +93,15 @@ class frontier_t {
   void set_number_of_elements(std::size_t const& n) {
     num_elements_ = n;
     work_hint_ = unknown_work;
+    ascending_ = false;
   }
+
+  /// The elements ascend (in long runs): operators::filter::select_range wrote them.  On a hot-first
+  /// numbered graph ascending ids are descending degrees, so 64 CONSECUTIVE elements make a tile of
+  /// near-equal, possibly all heavy, rows; the wide-level advance then deals its tiles across the
+  /// frontier instead (lane l of tile t takes element l * tiles + t).  Any other writer clears it.
+  bool ascending() const { return ascending_; }
+  void set_ascending(bool a) { ascending_ = a; }
 
   /**
    * @brief Upper bound of the sum of the degrees of the valid elements, when an
@@ -206,6 +214,7 @@ class frontier_t {
     std::swap(num_elements_, other.num_elements_);
     std::swap(resizing_factor_, other.resizing_factor_);
     std::swap(work_hint_, other.work_hint_);
+    std::swap(ascending_, other.ascending_);
   }
 
   std::vector<type_t> to_host() const {
@@ -228,6 +237,7 @@ class frontier_t {
   std::size_t num_elements_ = 0;
   float resizing_factor_ = 1.0f;
   unsigned long long work_hint_ = ~0ull;
+  bool ascending_ = false;
 };
 
 }  // namespace frontier

@@ -376,7 +376,7 @@ void execute(graph_t& G,
           }
           kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
               G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors,
-              (const unsigned long long*)nullptr);
+              (const unsigned long long*)nullptr, input_type == advance_io_type_t::vertices && input.ascending());
           GRX_HIP_CHECK(hipGetLastError());
           expanded = true;
         }
@@ -412,6 +412,8 @@ void execute(graph_t& G,
     }
   }
   GRX_HIP_CHECK(hipGetLastError());
+  if (!has_out && context.options().defer_sync_of_none_output)
+    return;  // enqueue only: the operator that follows fetches the counters and stops the clock
   clock.stop();
   if (has_out)
     detail::finish_output(output, holes, total, context);
@@ -515,7 +517,8 @@ bool enqueue_packed_settled(graph_t& G,
          context.stream()>>>(G, input, n_in_bound, n_in_device, chunks, chunk_capacity, hub_threshold,
                              chunk_edges, mask, cursors, counters);
   kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
-      G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, mask, cursors, n_in_device);
+      G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, mask, cursors, n_in_device,
+      false);
   GRX_HIP_CHECK(hipGetLastError());
   return true;
 }

@@ -164,13 +164,16 @@ void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
   clock.stop();
   unsigned long long* m = operators::advance::detail::fetch_counters(context);
   context.kernel_clock().collect();
-  if (m[k::C_OVERFLOW] != 0) {  // more matches than the frontier holds: grow and repeat (pred is pure here)
+  if (m[k::C_OVERFLOW] != 0) {
+    // more matches than the frontier holds: grow and repeat (pred is pure here).  (A deferred advance
+    // in front of this call cannot have raised the flag: without an output it writes nothing.)
     output.reserve((std::size_t)m[k::C_OUT]);
     select_range(G, n, pred, output, context);
     return;
   }
   output.set_number_of_elements((std::size_t)m[k::C_OUT]);
   output.set_work_hint(m[k::C_NEXT_WORK]);
+  output.set_ascending(true);
 }
 
 /// Frontier-level entry (reference filter.hxx:59-86).

@@ -190,6 +190,11 @@ struct operator_options_t {
   /// next one by one pass over the labels (operators::filter::select_range: sorted runs, degree sum
   /// for free); 0 = never.  Below it the advance packs its output as before.
   unsigned long long label_scan_min_work = 16ull << 20;
+  /// An advance WITHOUT an output frontier normally waits for its kernels like every operator.
+  /// true (set by a client around ONE such call, when an operator that fetches the counters follows
+  /// at once on the same stream -- operators::filter::select_range): it only enqueues; the next
+  /// operator's hand-off reports its overflow flags and closes its kernel-time interval.
+  bool defer_sync_of_none_output = false;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -208,13 +213,18 @@ struct kernel_clock_t {
       created = true;
     }
   }
+  bool running = false;  // started, not yet stopped: a deferred operator left its interval open
   void start(hipStream_t s) {
+    if (running)
+      return;  // the interval of a deferred operator goes on through this one
     ensure();
     GRX_HIP_CHECK(hipEventRecord(begin_, s));
+    running = true;
   }
   void stop(hipStream_t s) {
     GRX_HIP_CHECK(hipEventRecord(end_, s));
     pending = true;
+    running = false;
   }
   /// Call after the stream has been synchronised.
   void collect() {
