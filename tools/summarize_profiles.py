@@ -19,7 +19,7 @@ import collections, csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 PRE = os.path.join(ROOT, "profiles", f"r{rnd:02d}_bench_")
 os.makedirs(os.path.dirname(PRE), exist_ok=True)
 
@@ -34,7 +34,7 @@ def one(pattern):
 
 ADVANCE = ("block_mapped_kernel", "chunk_kernel", "classify_hubs_kernel", "expand_fused_kernel",
            "expand_settled_kernel", "rebuild_kernel", "wave_chunk_kernel", "pull_probe_kernel",
-           "pull_long_kernel")
+           "pull_long_kernel", "select_range_kernel")
 
 
 def attribute(name):
@@ -59,7 +59,9 @@ def attribute_all(names):
     """attribute() over dispatches in launch order.  A hub pre-pass (no functor in its template
     arguments) belongs to the client of the expansion kernel launched right after it.  A push BFS run
     (its dispatches end with reach_stats_kernel) that has a wide level but no expand_settled_kernel is
-    the call_every_edge formulation of bench.py's roofline leg: client "bfs_every_edge"."""
+    the call_every_edge formulation of bench.py's roofline leg: client "bfs_every_edge".  An SSSP run
+    with a bypass_kernel in it is the reference's two-pass formulation (advance + bypass filter,
+    grx_options.sssp_two_pass): client "sssp_two_pass" -- round 2 averaged both under "sssp"."""
     out = [attribute(n) for n in names]
     for i, (k, c) in enumerate(out):
         if k == "classify_hubs_kernel" and c == "-":
@@ -77,6 +79,10 @@ def attribute_all(names):
             for j in run:
                 if out[j][1] == "bfs":
                     out[j] = (out[j][0], "bfs_every_edge")
+        if any(out[j][0] == "bypass_kernel" for j in run):
+            for j in run:
+                if out[j][1] == "sssp":
+                    out[j] = (out[j][0], "sssp_two_pass")
         start = i + 1
     return out
 
@@ -102,7 +108,7 @@ with open(PRE + "kernel_trace_advance.csv", "w", newline="") as f:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         per_kernel[(k, c)][0] += 1
         per_kernel[(k, c)][1] += (e - s) / 1e3
-        if c in ("bfs", "bfs_every_edge", "sssp") and k in ADVANCE:
+        if c in ("bfs", "bfs_every_edge", "sssp", "sssp_two_pass") and k in ADVANCE:
             per_client_us[c] += (e - s) / 1e3
         if c in ("pagerank_push", "pagerank_pull"):
             per_client_us[c] += (e - s) / 1e3
@@ -113,6 +119,7 @@ with open(PRE + "kernel_trace_advance.csv", "w", newline="") as f:
                     r.get("VGPR_Count", ""), r.get("SGPR_Count", "")])
 stats_bench = bench_line(os.path.join(RAW, "stats.json"))
 json.dump(stats_bench, open(PRE + "line.json", "w"))
+json.dump(stats_bench, open(os.path.join(ROOT, "profiles", "latest_bench_line.json"), "w"))  # bench.py: cpu_baseline_n1
 with open(PRE + "kernel_by_client.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "client", "dispatches", "total_us", "mean_us"])
@@ -124,8 +131,9 @@ trace = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
          "bfs_advance_us_per_traversal": per_client_us["bfs"] / runs["bfs"] if runs.get("bfs") else None,
          "bfs_every_edge_advance_us_per_traversal":
              per_client_us["bfs_every_edge"] / runs["bfs_call_every_edge"] if runs.get("bfs_call_every_edge") else None,
-         "sssp_advance_us_per_traversal":
-             per_client_us["sssp"] / (runs["sssp"] + runs.get("sssp_two_pass", 0)) if runs.get("sssp") else None,
+         "sssp_advance_us_per_traversal": per_client_us["sssp"] / runs["sssp"] if runs.get("sssp") else None,
+         "sssp_two_pass_advance_us_per_traversal":
+             per_client_us["sssp_two_pass"] / runs["sssp_two_pass"] if runs.get("sssp_two_pass") else None,
          "pagerank_push_us_per_iteration":
              per_client_us["pagerank_push"] / pr["push"]["iterations"] if pr.get("push") else None,
          "pagerank_pull_us_per_iteration":
@@ -136,8 +144,8 @@ trace = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
                         "sssp_kernel_ms": stats_bench.get("roofline_sssp", {}).get("kernel_ms"),
                         "pagerank_push_ms_per_iteration": pr.get("push", {}).get("ms_per_iteration"),
                         "pagerank_pull_ms_per_iteration": pr.get("pull", {}).get("ms_per_iteration")},
-         "note": "sssp: the one-pass and the two-pass (reference formulation) runs of the roofline leg share "
-                 "the relax kernels' names; the figure is the mean over all of them"}
+         "note": "sssp = the one-pass runs (packed labels); the reference's two-pass formulation is told apart "
+                 "by the bypass_kernel of its runs and reported separately"}
 
 
 # ---- 2. PMC passes ----------------------------------------------------------------------------------
@@ -195,7 +203,8 @@ def traffic(client, per, kernels=None, unit="traversal"):
 
 tr = {"bfs": traffic("bfs", pmc_runs.get("bfs"), ADVANCE),
       "bfs_every_edge": traffic("bfs_every_edge", pmc_runs.get("bfs_call_every_edge"), ADVANCE),
-      "sssp": traffic("sssp", (pmc_runs.get("sssp", 0) + pmc_runs.get("sssp_two_pass", 0)) or None, ADVANCE),
+      "sssp": traffic("sssp", pmc_runs.get("sssp"), ADVANCE),
+      "sssp_two_pass": traffic("sssp_two_pass", pmc_runs.get("sssp_two_pass"), ADVANCE),
       "pagerank_push": traffic("pagerank_push", pmc_pr.get("push", {}).get("iterations"), None, "iteration"),
       "pagerank_pull": traffic("pagerank_pull", pmc_pr.get("pull", {}).get("iterations"), None, "iteration")}
 # calibration on the gather probe: bench.py calls grx_measure_gather_rate twice (agent-scope and plain
@@ -221,7 +230,7 @@ with open(PRE + "pmc_l2.csv", "w", newline="") as f:
     w.writerow(["pass", "dispatch", "kernel", "client", "counter", "value"])
     for name, table in (("l2busy", busy_disp), ("l2hit", hit_disp)):
         for did, d in table.items():
-            if d["client"] in ("bfs", "bfs_every_edge", "sssp", "pagerank_push", "pagerank_pull", "probe"):
+            if d["client"] in ("bfs", "bfs_every_edge", "sssp", "sssp_two_pass", "pagerank_push", "pagerank_pull", "probe"):
                 for cn, cv in d["counters"].items():
                     w.writerow([name, did, d["kernel"], d["client"], cn, f"{cv:.0f}"])
 
@@ -259,8 +268,8 @@ latest = {
                     "pagerank_bytes_per_iteration": pmc_pr.get("algorithmic_bytes_per_iteration")},
     "trace": trace,
     "l2": {"busy_frac_bfs_advance": l2("bfs")["busy_frac"], "hit_rate_bfs_advance": l2("bfs")["hit_rate"],
-           "by_client": {c: l2(c) for c in ("bfs", "bfs_every_edge", "sssp", "pagerank_push", "pagerank_pull",
-                                            "probe")},
+           "by_client": {c: l2(c) for c in ("bfs", "bfs_every_edge", "sssp", "sssp_two_pass", "pagerank_push",
+                                            "pagerank_pull", "probe")},
            "reading": "TCC_BUSY/TCC_CYCLE summed over the 128 L2 channels and all dispatches of the client"},
 }
 json.dump(latest, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
