@@ -3,10 +3,29 @@
 (VERDICT r2 item 5): the bare scatter acc[dst] += w over the directed R-MAT graph with the edges into
 the K HOTTEST destinations taken out of the atomic stream (redirected to uniformly random cold
 destinations: an ideal K-entry combiner absorbs exactly those, the rest still goes to memory).
-usage: pr_hot_probe.py [scale]"""
+usage: pr_hot_probe.py [scale]          (on the GPU box)
+       pr_hot_probe.py --simulate       (CPU, numpy): what a FIRST-COME direct-mapped table of S slots
+                                        absorbs of one workgroup's share of the edges (destinations
+                                        drawn from the R-MAT column law, every id bit 1 with p = 0.24)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+
+if "--simulate" in sys.argv:
+    rng = np.random.default_rng(1)
+    scale = 24
+    for share in (262144, 1048576):
+        d = ((rng.random((share, scale)) < 0.24) * (1 << np.arange(scale))).sum(1).astype(np.int64)
+        for slots in (1024, 2048, 4096, 8192, 16384):
+            h = (d * 2654435761 % (1 << 32)) >> (32 - int(np.log2(slots)))
+            _, first = np.unique(h, return_index=True)       # the first comer owns the slot
+            owner = np.full(slots, -1, np.int64)
+            owner[h[first]] = d[first]
+            absorbed = int((owner[h] == d).sum()) - len(first)
+            print(f"workgroup share {share} edges, {slots} slots: {absorbed / share:.1%} absorbed")
+    sys.exit(0)
+
+import torch
 import essentials_amd as ea
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
