@@ -61,6 +61,8 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       enactor.bound_filter = o.call_every_edge == 0;
       if (const char* e = std::getenv("GRX_SSSP_BOUND_FILTER"))
         enactor.bound_filter = std::atoi(e) != 0;
+      if (const char* e = std::getenv("GRX_SSSP_EARLY_LIVE"))
+        enactor.early_live = std::atoi(e) != 0;
       if (const char* e = std::getenv("GRX_SSSP_BOUND_FROM"))
         enactor.bound_from = std::atoi(e);
       const float ms = enactor.enact();

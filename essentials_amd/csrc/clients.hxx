@@ -533,6 +533,7 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
   bool two_pass = false;  // true: advance + bypass filter, as reference algorithms/sssp.hxx does
   bool bound_filter = true;  // wide iterations: 2-byte bound mirror in front of the labels (packed form)
   int bound_from = -1;       // >= 0: first iteration that uses it (experiments); -1: by edges expanded so far
+  bool early_live = true;    // the batched form before that point too (hot-first graphs), live labels beyond the image
 
   sssp_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                  enactor_properties_t props = enactor_properties_t())
@@ -666,7 +667,11 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
                             : work != frontier_t::unknown_work &&
                                   4 * ((unsigned long long)P->log.edges_expanded - work) >=  // before this one
                                       (unsigned long long)G.get_number_of_edges();
-        if (lb == load_balance_t::block_mapped && bound_filter && reached_enough &&
+        // before that point the batched form still pays on a hot-first numbered graph when the ids the
+        // image does not cover are asked for their LIVE label instead of the (mostly absent) bound:
+        // the frontier of such an iteration is the hubs, whose bounds the image holds
+        const bool early = !reached_enough && early_live && G.properties.leading_connected != 0;
+        if (lb == load_balance_t::block_mapped && bound_filter && (reached_enough || early) &&
             ctx->options().settled_filter &&
             !ctx->options().holes_layout && work != frontier_t::unknown_work &&
             work >= ctx->options().settled_min_work) {
@@ -685,23 +690,37 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
             const unsigned b = bound;
             return b != 0xffffu && problem_type::ordered_bits(through) >= (b << 16);
           };
-          auto not_shorter = [cached, bound16] __device__(vertex_t const& src, vertex_t const& dst,
-                                                          edge_t const& edge, weight_t const& w) -> bool {
-            return cached(src, dst, edge, w, bound16[dst]);
+          const bool scan = ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work;
+          auto run = [&](auto hinted) {
+            if (scan) {
+              // no output frontier: the round tag in a label's low word says "lowered in this round"
+              ctx->options().defer_sync_of_none_output = true;  // scan_improved below is its hand-off
+              operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                          operators::advance_io_type_t::vertices,
+                                          operators::advance_io_type_t::none>(G, E, hinted, context);
+              ctx->options().defer_sync_of_none_output = false;
+              scan_improved(packed, this_round, context);
+            } else {
+              operators::advance::execute<lb>(G, E, hinted, context);
+            }
           };
-          auto hinted = operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter, cached, bound16,
-                                                                  (std::size_t)G.get_number_of_vertices());
-          if (ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work) {
-            // no output frontier: the round tag in a label's low word says "lowered in this round"
-            ctx->options().defer_sync_of_none_output = true;  // scan_improved below is its hand-off
-            operators::advance::execute<lb, operators::advance_direction_t::forward,
-                                        operators::advance_io_type_t::vertices,
-                                        operators::advance_io_type_t::none>(G, E, hinted, context);
-            ctx->options().defer_sync_of_none_output = false;
-            scan_improved(packed, this_round, context);
-            return;
+          if (reached_enough) {
+            auto not_shorter = [cached, bound16] __device__(vertex_t const& src, vertex_t const& dst,
+                                                            edge_t const& edge, weight_t const& w) -> bool {
+              return cached(src, dst, edge, w, bound16[dst]);
+            };
+            run(operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter, cached, bound16,
+                                                          (std::size_t)G.get_number_of_vertices()));
+          } else {
+            auto not_shorter_live = [packed] __device__(vertex_t const& src, vertex_t const& dst,
+                                                        edge_t const& edge, weight_t const& w) -> bool {
+              const weight_t through =
+                  problem_type::from_ordered_bits((unsigned)(packed[src] >> 32)) + w;
+              return problem_type::ordered_bits(through) >= (unsigned)(packed[dst] >> 32);
+            };
+            run(operators::advance::with_bounds<vertex_t>(relax_packed, not_shorter_live, cached, bound16,
+                                                          (std::size_t)G.get_number_of_vertices()));
           }
-          operators::advance::execute<lb>(G, E, hinted, context);
           return;
         }
       }
