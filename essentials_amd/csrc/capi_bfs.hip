@@ -72,9 +72,20 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
         stats->levels_recorded = problem.log.levels < 64 ? problem.log.levels : 64;
         for (int i = 0; i < stats->levels_recorded; ++i)
           stats->frontier_slots[i] = problem.log.input_slots[i];
-        // the first frontier ({source}) carries no work hint: add the source's own degree
-        stats->edges_expanded =
-            problem.log.edges_expanded + reach_stats(g, d_distances, (int32_t)INT32_MAX, source, ctx->single(), stats);
+        // the first frontier ({source}) carries no work hint: add the source's own degree.  A push
+        // search with packed frontiers discovers every vertex exactly once and every level's frontier
+        // came with the degree sum of its vertices: the counts are sums over the level log, the
+        // source's degree was left in pinned memory by the reset pass -- no statistics pass
+        const unsigned long long* facts = ctx->single().workspace().run_facts();
+        if (!o.direction_optimized && !o.holes_layout && o.max_iterations == 0 &&
+            problem.log.unknown_work_levels == 1) {
+          stats->vertices_reached = problem.log.slots_total;
+          stats->edges_traversed = problem.log.edges_expanded + (long long)facts[0];
+          stats->edges_expanded = stats->edges_traversed;
+        } else {
+          stats->edges_expanded = problem.log.edges_expanded +
+                                  reach_stats(g, d_distances, (int32_t)INT32_MAX, source, ctx->single(), stats);
+        }
       }
       return (int)GRX_OK;
     });

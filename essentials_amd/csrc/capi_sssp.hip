@@ -50,6 +50,8 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
       if (const char* e = std::getenv("GRX_SSSP_PACKED"))
         packed = std::atoi(e) != 0;
       problem.packed_labels = packed && o.sssp_two_pass == 0;
+      // the unpacking pass at the end of a packed run also counts what the run reached
+      problem.collect_reach = stats != nullptr && problem.packed_labels;
       problem.init();
       problem.reset();
       enactor_properties_t props;
@@ -76,8 +78,15 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
         for (int i = 0; i < stats->levels_recorded; ++i)
           stats->frontier_slots[i] = problem.log.input_slots[i];
         // the first frontier ({source}) carries no work hint: add the source's own degree
-        stats->edges_expanded =
-            problem.log.edges_expanded + reach_stats(g, d_distances, FLT_MAX, source, ctx->single(), stats);
+        const unsigned long long* facts = ctx->single().workspace().run_facts();
+        if (problem.collect_reach && facts[3] == 1ull) {  // left in pinned memory by unpack()
+          stats->vertices_reached = (int64_t)facts[1];
+          stats->edges_traversed = (int64_t)facts[2];
+          stats->edges_expanded = problem.log.edges_expanded + (long long)facts[0];
+        } else {
+          stats->edges_expanded =
+              problem.log.edges_expanded + reach_stats(g, d_distances, FLT_MAX, source, ctx->single(), stats);
+        }
       }
       return (int)GRX_OK;
     });

@@ -34,11 +34,16 @@ struct level_log_t {
   long long input_slots[max_levels] = {0};
   long long edges_expanded = 0;   // sum of the input frontiers' work hints (exact when an advance
                                   // produced the frontier; the source's own degree is added by the caller)
+  long long slots_total = 0;      // sum of the input frontiers' lengths, all levels
+  int unknown_work_levels = 0;    // levels whose frontier carried no work hint (level 0 always)
   void note(std::size_t slots, unsigned long long work = ~0ull) {
     if (levels < max_levels)
       input_slots[levels] = (long long)slots;
+    slots_total += (long long)slots;
     if (work != ~0ull)
       edges_expanded += (long long)work;
+    else
+      ++unknown_work_levels;
     ++levels;
   }
 };
@@ -86,18 +91,25 @@ struct bfs_problem_t : gunrock::problem_t<graph_t> {
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
     // one pass, enqueued on the context's stream ahead of the traversal: nothing to wait for
     const vertex_t s = source;
+    // the source's degree, for the run's statistics: left in pinned memory by the reset pass itself
+    auto G = this->get_graph();
+    unsigned long long* facts = ctx->workspace().run_facts();
     if (byte_labels) {
       unsigned* w = bytes.data();
       hip::for_each_index(
-          (n + 3) / 4, [w, s] __device__(std::size_t i) {
+          (n + 3) / 4, [w, s, G, facts] __device__(std::size_t i) {
             w[i] = (std::size_t)(s >> 2) == i ? ~(0xFFu << ((s & 3) * 8)) : 0xFFFFFFFFu;
+            if ((std::size_t)(s >> 2) == i)
+              facts[0] = (unsigned long long)G.get_number_of_neighbors(s);
           },
           ctx->stream());
     } else {
       vertex_t* d = labels();
       hip::for_each_index(
-          n, [d, s] __device__(std::size_t i) {
+          n, [d, s, G, facts] __device__(std::size_t i) {
             d[i] = (vertex_t)i == s ? vertex_t(0) : std::numeric_limits<vertex_t>::max();
+            if ((vertex_t)i == s)
+              facts[0] = (unsigned long long)G.get_number_of_neighbors(s);
           },
           ctx->stream());
     }
@@ -397,6 +409,55 @@ struct bfs_do_enactor_t : gunrock::enactor_t<problem_type> {
 // ---------------------------------------------------------------------------
 // single-source shortest paths (Bellman-Ford style frontier relaxation)
 // ---------------------------------------------------------------------------
+/// sssp_problem_t::unpack with the run's statistics folded in: distance[to[i]] <- the packed label's
+/// distance, and (reached vertices, sum of their degrees) -> pinned run facts by the LAST workgroup to
+/// finish (ticket on a device counter): no separate statistics pass, no hand-off to wait for.
+template <typename vertex_t, typename weight_t, typename graph_t, typename decode_t>
+__global__ void __launch_bounds__(1024)
+    unpack_with_stats_kernel(graph_t G, std::size_t n, const unsigned long long* packed, unsigned far_bits,
+                             weight_t* out, const vertex_t* to, decode_t decode, unsigned long long* counters,
+                             unsigned long long* facts) {
+  __shared__ unsigned long long s_v[16], s_e[16];
+  unsigned long long reached = 0, edges = 0;
+  for (std::size_t i = blockIdx.x * (std::size_t)1024 + threadIdx.x; i < n; i += (std::size_t)gridDim.x * 1024) {
+    const unsigned bits = (unsigned)(packed[i] >> 32);
+    out[to ? (std::size_t)to[i] : i] = decode(bits);
+    if (bits != far_bits) {
+      ++reached;
+      edges += (unsigned long long)G.get_number_of_neighbors((vertex_t)i);
+    }
+  }
+  reached = hip::wave_sum(reached);
+  edges = hip::wave_sum(edges);
+  if ((threadIdx.x & 63) == 0) {
+    s_v[threadIdx.x / 64] = reached;
+    s_e[threadIdx.x / 64] = edges;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long v = 0, e = 0;
+    for (int k = 0; k < 16; ++k) {
+      v += s_v[k];
+      e += s_e[k];
+    }
+    namespace k = hip::kernels;
+    if (v)
+      atomicAdd(&counters[k::C_OUT], v);
+    if (e)
+      atomicAdd(&counters[k::C_WORK], e);
+    __threadfence();
+    if (atomicAdd(&counters[k::C_SELECT], 1ull) + 1ull == (unsigned long long)gridDim.x) {
+      // last one out: totals to pinned memory, the three counters back to zero (the invariant
+      // between operators)
+      facts[1] = atomicExch(&counters[k::C_OUT], 0ull);
+      facts[2] = atomicExch(&counters[k::C_WORK], 0ull);
+      atomicExch(&counters[k::C_SELECT], 0ull);
+      __threadfence_system();
+      facts[3] = 1ull;
+    }
+  }
+}
+
 template <typename graph_t>
 struct sssp_problem_t : gunrock::problem_t<graph_t> {
   using vertex_t = typename graph_t::vertex_type;
@@ -425,6 +486,9 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   // renumbered graph (see bfs_problem_t): distances are delivered as distance[scatter_to[v]]
   const vertex_t* scatter_to = nullptr;
   hip::device_array_t<weight_t> own_distance;
+  /// unpack() also counts the reached vertices and their degrees into the context's pinned run
+  /// facts (packed form): the caller reads them after enact() instead of running a statistics pass.
+  bool collect_reach = false;
   /// The float array the two-word form runs in (the graph's numbering).
   weight_t* run_distance() { return scatter_to ? own_distance.data() : distance; }
 
@@ -483,8 +547,14 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
       unsigned long long* p = packed.data();
       const unsigned long long zero = (unsigned long long)ordered_bits(weight_t(0)) << 32;
       const unsigned long long far = (unsigned long long)ordered_bits(std::numeric_limits<weight_t>::max()) << 32;
+      auto G = this->get_graph();
+      unsigned long long* facts = ctx->workspace().run_facts();  // [0] <- the source's degree
       hip::for_each_index(
-          n, [p, s, zero, far] __device__(std::size_t i) { p[i] = (vertex_t)i == s ? zero : far; },
+          n, [p, s, zero, far, G, facts] __device__(std::size_t i) {
+            p[i] = (vertex_t)i == s ? zero : far;
+            if ((vertex_t)i == s)
+              facts[0] = (unsigned long long)G.get_number_of_neighbors(s);
+          },
           ctx->stream());
     } else {
       weight_t* d = run_distance();
@@ -506,6 +576,18 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
     const unsigned long long* p = packed.data();
     weight_t* d = distance;
     const vertex_t* to = scatter_to;
+    if (packed_labels && collect_reach) {
+      auto G = this->get_graph();
+      unsigned long long* facts = ctx->workspace().run_facts();
+      facts[3] = 0ull;
+      const unsigned far_bits = ordered_bits(std::numeric_limits<weight_t>::max());
+      const unsigned grid = (unsigned)std::min<std::size_t>((n + 1023) / 1024, (std::size_t)ctx->compute_units() * 2);
+      unpack_with_stats_kernel<vertex_t, weight_t><<<grid ? grid : 1, 1024, 0, ctx->stream()>>>(
+          G, n, p, far_bits, d, to, [] __device__(unsigned bits) { return from_ordered_bits(bits); },
+          ctx->workspace().counters(), facts);
+      GRX_HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (packed_labels) {
       if (to)
         hip::for_each_index(

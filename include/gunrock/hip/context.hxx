@@ -104,6 +104,10 @@ class workspace_t {
   }
   /// Pinned host mirror of the counters.
   unsigned long long* mirror() { return mirror_.data(); }
+  /// Pinned words a client's own kernels may leave facts of a run in (the host reads them after the
+  /// run's final synchronisation: no hand-off kernel, no extra wait): [0] degree of the source,
+  /// [1] vertices reached, [2] sum of their degrees, [3] set to 1 when [1] and [2] are valid.
+  unsigned long long* run_facts() { return run_facts_.data(); }
   /// Slot of the mirror that carries the hand-off sequence number, and the next number.
   static constexpr std::size_t sequence_slot = 31;
   unsigned long long next_sequence() { return ++sequence_; }
@@ -149,6 +153,7 @@ class workspace_t {
  private:
   hip::buffer_t<unsigned long long> counters_;
   hip::pinned_t<unsigned long long> mirror_{n_counters};
+  hip::pinned_t<unsigned long long> run_facts_{8};
   unsigned long long sequence_ = 0;
   hip::buffer_t<unsigned char> scratch_;
   hip::buffer_t<unsigned char> queue_;

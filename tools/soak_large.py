@@ -32,6 +32,11 @@ while time.time() - t0 < budget:
     ok &= torch.equal(d, ref)
     w, _ = ea.sssp(ctx, g, s, options=o)
     ok &= torch.equal(w.view(torch.int32), wref.view(torch.int32))
+    # the forms that stand for the unchanged reference clients: caller's numbering, every edge / two passes
+    d, _ = ea.bfs(ctx, g, s, options=ea.Options(call_every_edge=True))
+    ok &= torch.equal(d, ref)
+    w, _ = ea.sssp(ctx, g, s, options=ea.Options(sssp_two_pass=True))
+    ok &= torch.equal(w.view(torch.int32), wref.view(torch.int32))
     dp = torch.empty(n, dtype=torch.int32, device="cuda"); trav.run(OP_BFS, s, dp)
     ok &= torch.equal(dp, ref)
     wp = torch.empty(n, dtype=torch.float32, device="cuda"); trav.run(OP_SSSP, s, wp)
