@@ -200,7 +200,7 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         work >= ctx->options().settled_min_work) {
       {  // part of this level's advance: timed with it when kernels are timed
         operators::advance::detail::clocked_t clock(*ctx);
-        settled.rebuild((std::size_t)G.get_number_of_vertices(), has_depth, *ctx);
+        settled.refresh((std::size_t)G.get_number_of_vertices(), has_depth, *ctx);
         clock.stop();
       }
       if (ctx->options().label_scan_min_work && work >= ctx->options().label_scan_min_work) {
@@ -217,7 +217,14 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         const std::size_t n_scan = G.properties.leading_connected
                                        ? (std::size_t)G.properties.leading_connected
                                        : (std::size_t)G.get_number_of_vertices();
-        operators::filter::select_range(G, n_scan, found_now, *E->get_output_frontier(), *ctx);
+        // the same pass leaves the NEXT level's settled bitmap (what rebuild() would compute then:
+        // has_depth as it stands after this level) when the graph is larger than the image
+        std::size_t bit_limit = 0;
+        unsigned long long* bit_words = nullptr;
+        if ((std::size_t)G.get_number_of_vertices() >= operators::advance::settled_max_ids)
+          bit_words = settled.prepare((std::size_t)G.get_number_of_vertices(), bit_limit);
+        operators::filter::select_range(G, n_scan, found_now, *E->get_output_frontier(), *ctx,
+                                        hip::kernels::select_no_each_t(), has_depth, bit_words, bit_limit);
         E->swap_frontier_buffers();
         return;
       }
@@ -483,6 +490,7 @@ struct sssp_problem_t : gunrock::problem_t<graph_t> {
   // is not below that bound without touching the label (section 5 of DESIGN.md: the wide SSSP
   // iterations run at the fabric's rate of 128-byte label lines).
   hip::device_array_t<unsigned short> bound16;
+  bool bounds_fresh = false;  // the previous iteration's label scan has just written them
   // renumbered graph (see bfs_problem_t): distances are delivered as distance[scatter_to[v]]
   const vertex_t* scatter_to = nullptr;
   hip::device_array_t<weight_t> own_distance;
@@ -637,14 +645,24 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
   /// label carries this round's tag (operators::filter::select_range), then swap.
   void scan_improved(const unsigned long long* packed, unsigned this_round, gcuda::multi_context_t& context) {
     auto E = this->get_enactor();
-    auto G = this->get_problem()->get_graph();
+    auto P = this->get_problem();
+    auto G = P->get_graph();
     auto ctx = context.get_context(0);
     const std::size_t n_scan = G.properties.leading_connected ? (std::size_t)G.properties.leading_connected
                                                               : (std::size_t)G.get_number_of_vertices();
     auto lowered_now = [packed, this_round] __device__(vertex_t const& v) -> bool {
       return (unsigned)packed[v] == this_round;
     };
-    operators::filter::select_range(G, n_scan, lowered_now, *E->get_output_frontier(), *ctx);
+    // the same pass leaves the next iteration's 2-byte bounds (snapshot_bounds() of the labels as
+    // they stand now); vertices without edges are never a destination, their bounds are not read
+    unsigned short* bound16 = P->bound16.data();
+    auto bound_of = [packed, bound16] __device__(vertex_t const& v) {
+      const unsigned bits = (unsigned)(packed[v] >> 32);
+      const unsigned up = (bits >> 16) + ((bits & 0xffffu) ? 1u : 0u);
+      bound16[v] = (unsigned short)(up > 0xffffu ? 0xffffu : up);
+    };
+    operators::filter::select_range(G, n_scan, lowered_now, *E->get_output_frontier(), *ctx, bound_of);
+    P->bounds_fresh = true;
     E->swap_frontier_buffers();
   }
 
@@ -757,11 +775,12 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
             ctx->options().settled_filter &&
             !ctx->options().holes_layout && work != frontier_t::unknown_work &&
             work >= ctx->options().settled_min_work) {
-          {  // part of this iteration's advance: timed with it when kernels are timed
+          if (!P->bounds_fresh) {  // part of this iteration's advance: timed with it when kernels are timed
             operators::advance::detail::clocked_t clock(*ctx);
             P->snapshot_bounds();
             clock.stop();
           }
+          P->bounds_fresh = false;
           const unsigned short* bound16 = P->bound16.data();
           // PURE: "relax_packed would return false for this edge and change nothing" -- the
           // candidate is not below an upper bound of the destination's distance (0xffff: no bound)

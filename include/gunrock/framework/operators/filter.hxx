@@ -141,34 +141,46 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output,
  * The engine extension behind "run a wide level without an output frontier, then name what it found".
  * pred is called exactly once per v, in no particular order.  Synchronous.
  */
-template <typename graph_t, typename pred_t, typename frontier_t>
+template <typename graph_t, typename pred_t, typename frontier_t,
+          typename each_t = ::gunrock::hip::kernels::select_no_each_t,
+          typename bit_t = ::gunrock::hip::kernels::select_no_bit_t>
 void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
-                  gcuda::standard_context_t& context) {
+                  gcuda::standard_context_t& context, each_t each = each_t(), bit_t bit = bit_t(),
+                  unsigned long long* bit_words = nullptr, std::size_t bit_limit = 0,
+                  std::size_t n_visit = 0) {
   namespace k = ::gunrock::hip::kernels;
   using vertex_t = typename frontier_t::type_t;
-  if (n == 0) {
+  // side products (compact_kernels.hxx): `each` for every id below n_visit (>= n; default n), bit i
+  // of bit_words <- bit(i) for i < bit_limit (a multiple of 64, <= the ids visited)
+  if (n_visit < n)
+    n_visit = n;
+  if (n_visit < bit_limit)
+    n_visit = bit_limit;
+  if (n_visit == 0) {
     output.set_number_of_elements(0);
     output.set_work_hint(0);
     return;
   }
   if (output.get_capacity() < 64)
     output.reserve(64);
-  const std::size_t chunks = (n + k::SEL_CHUNK - 1) / k::SEL_CHUNK;
+  const std::size_t chunks = (n_visit + k::SEL_CHUNK - 1) / k::SEL_CHUNK;
   const std::size_t cap = (std::size_t)context.compute_units() * 2;
   operators::advance::detail::clocked_t clock(context);  // it IS a level's output path: timed with the advances
   k::select_range_kernel<vertex_t><<<(unsigned)(chunks < cap ? chunks : cap), k::SEL_BLOCK, 0,
-                                     context.stream()>>>(G, n, pred, output.data(), output.get_capacity(),
+                                     context.stream()>>>(G, n_visit, pred, output.data(), output.get_capacity(),
                                                          context.workspace().counters(), (int)k::C_OUT,
-                                                         (int)k::C_NEXT_WORK, (int)k::C_OVERFLOW);
+                                                         (int)k::C_NEXT_WORK, (int)k::C_OVERFLOW, n, each, bit,
+                                                         bit_words, bit_limit);
   GRX_HIP_CHECK(hipGetLastError());
   clock.stop();
   unsigned long long* m = operators::advance::detail::fetch_counters(context);
   context.kernel_clock().collect();
   if (m[k::C_OVERFLOW] != 0) {
-    // more matches than the frontier holds: grow and repeat (pred is pure here).  (A deferred advance
-    // in front of this call cannot have raised the flag: without an output it writes nothing.)
+    // more matches than the frontier holds: grow and repeat (pred, each and bit are idempotent here).
+    // (A deferred advance in front of this call cannot have raised the flag: without an output it
+    // writes nothing.)
     output.reserve((std::size_t)m[k::C_OUT]);
-    select_range(G, n, pred, output, context);
+    select_range(G, n, pred, output, context, each, bit, bit_words, bit_limit, n_visit);
     return;
   }
   output.set_number_of_elements((std::size_t)m[k::C_OUT]);

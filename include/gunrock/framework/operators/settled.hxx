@@ -183,10 +183,33 @@ class settled_filter_t {
     return settled_view_t<vertex_t>{reinterpret_cast<const unsigned*>(words_.data()), limit_};
   }
   void clear() { limit_ = 0; }
+  /// Another pass is about to write the bitmap (operators::filter::select_range with a bit
+  /// predicate): storage for `n_vertices`, returns the word array; `limit` ids are covered.  The
+  /// next rebuild() is then skipped once (the bits are those rebuild() would compute now).
+  unsigned long long* prepare(std::size_t n_vertices, std::size_t& limit) {
+    std::size_t ids = n_vertices < settled_max_ids ? n_vertices : settled_max_ids;
+    ids = (ids + 127) / 128 * 128;
+    if (words_.size() < ids / 64)
+      words_.resize(ids / 64);
+    limit_ = (vertex_t)ids;
+    limit = ids;
+    fresh_ = true;
+    return words_.data();
+  }
+  /// rebuild() unless a prepare()d pass has just written the bits.
+  template <typename pred_t>
+  void refresh(std::size_t n_vertices, pred_t pred, gcuda::standard_context_t& context) {
+    if (fresh_) {
+      fresh_ = false;
+      return;
+    }
+    rebuild(n_vertices, pred, context);
+  }
 
  private:
   hip::device_array_t<unsigned long long> words_;
   vertex_t limit_ = 0;
+  bool fresh_ = false;
 };
 
 }  // namespace advance

@@ -19,6 +19,8 @@
  */
 #pragma once
 
+#include <type_traits>
+
 #include <gunrock/hip/primitives.hxx>
 #include <gunrock/util/type_limits.hxx>
 
@@ -134,11 +136,25 @@ constexpr int SEL_ITEMS = 8;
 constexpr int SEL_CHUNK = SEL_BLOCK * SEL_ITEMS;  // 8192 ids per claim
 constexpr int SEL_WAVES = SEL_BLOCK / wave_size;  // 16
 
-template <typename vertex_t, typename graph_t, typename pred_t>
+/// Side products of the same pass (both optional): `each(i)` runs once for every id (lane-local side
+/// effects: SSSP writes the 2-byte bound of i for the next iteration), and the ballot of `bit(i)` is
+/// stored as bit i of `words` for i < bit_limit (BFS: the settled bitmap of the next level) -- the
+/// label array is read once for all three.
+struct select_no_each_t {
+  template <typename vertex_t>
+  __device__ __forceinline__ void operator()(vertex_t const&) const {}
+};
+struct select_no_bit_t {
+  template <typename vertex_t>
+  __device__ __forceinline__ bool operator()(vertex_t const&) const { return false; }
+};
+
+template <typename vertex_t, typename graph_t, typename pred_t, typename each_t, typename bit_t>
 __global__ void __launch_bounds__(SEL_BLOCK)
     select_range_kernel(graph_t G, std::size_t n, pred_t pred, vertex_t* __restrict__ out,
                         std::size_t capacity, unsigned long long* counters, int cursor_slot,
-                        int work_slot, int overflow_slot) {
+                        int work_slot, int overflow_slot, std::size_t n_select, each_t each, bit_t bit,
+                        unsigned long long* __restrict__ words, std::size_t bit_limit) {
   __shared__ unsigned s_count[SEL_ITEMS * SEL_WAVES];   // matches per (k, wave), then their prefix
   __shared__ unsigned long long s_base;
   __shared__ unsigned long long s_work[SEL_WAVES];
@@ -150,7 +166,15 @@ __global__ void __launch_bounds__(SEL_BLOCK)
 #pragma unroll
     for (int k = 0; k < SEL_ITEMS; ++k) {
       const std::size_t i = chunk * SEL_CHUNK + (std::size_t)k * SEL_BLOCK + tid;
-      const bool keep = i < n && pred((vertex_t)i);
+      if (i < n)
+        each((vertex_t)i);
+      if constexpr (!std::is_same<bit_t, select_no_bit_t>::value) {
+        const unsigned long long word = __ballot(i < n && bit((vertex_t)i));
+        if (lane == 0 && i < bit_limit)  // i is a multiple of 64 on lane 0; bit_limit is one too
+          words[i / wave_size] = word;
+      }
+      // ids in [n_select, n) are visited for the side products only
+      const bool keep = i < n_select && pred((vertex_t)i);
       mask[k] = __ballot(keep);
       if (keep)
         work += (unsigned long long)G.get_number_of_neighbors((vertex_t)i);
