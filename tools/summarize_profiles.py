@@ -69,11 +69,11 @@ def attribute_all(names):
                 if k2 in ("expand_fused_kernel", "expand_settled_kernel"):
                     out[i] = (k, c2)
                     break
-    start = 0
-    for i, (k, c) in enumerate(out + [("reach_stats_kernel", "-")]):
-        if k != "reach_stats_kernel":
-            continue
-        run = range(start, min(i, len(out)))
+    # one run = from a problem's reset pass (index_kernel over `...problem_t<...>::reset()`'s lambda)
+    # to the next one; round 2 cut at reach_stats_kernel, which the default forms no longer launch
+    starts = [i for i, n in enumerate(names) if "problem_t<" in n and "::reset()" in n]
+    for a, b in zip(starts, starts[1:] + [len(out)]):
+        run = range(a, b)
         mine = [out[j][0] for j in run if out[j][1] == "bfs"]
         if "expand_fused_kernel" in mine and "expand_settled_kernel" not in mine:
             for j in run:
@@ -83,7 +83,6 @@ def attribute_all(names):
             for j in run:
                 if out[j][1] == "sssp":
                     out[j] = (out[j][0], "sssp_two_pass")
-        start = i + 1
     return out
 
 
