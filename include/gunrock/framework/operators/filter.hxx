@@ -161,8 +161,8 @@ void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
     output.set_work_hint(0);
     return;
   }
-  if (output.get_capacity() < 64)
-    output.reserve(64);
+  if (output.get_capacity() < n)  // at most every candidate is selected: the pass runs ONCE
+    output.reserve(n);
   const std::size_t chunks = (n_visit + k::SEL_CHUNK - 1) / k::SEL_CHUNK;
   const std::size_t cap = (std::size_t)context.compute_units() * 2;
   operators::advance::detail::clocked_t clock(context);  // it IS a level's output path: timed with the advances
@@ -175,14 +175,7 @@ void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
   clock.stop();
   unsigned long long* m = operators::advance::detail::fetch_counters(context);
   context.kernel_clock().collect();
-  if (m[k::C_OVERFLOW] != 0) {
-    // more matches than the frontier holds: grow and repeat (pred, each and bit are idempotent here).
-    // (A deferred advance in front of this call cannot have raised the flag: without an output it
-    // writes nothing.)
-    output.reserve((std::size_t)m[k::C_OUT]);
-    select_range(G, n, pred, output, context, each, bit, bit_words, bit_limit, n_visit);
-    return;
-  }
+  error::throw_if_exception(m[k::C_OVERFLOW] != 0, "select_range: output frontier capacity exceeded");
   output.set_number_of_elements((std::size_t)m[k::C_OUT]);
   output.set_work_hint(m[k::C_NEXT_WORK]);
   output.set_ascending(true);

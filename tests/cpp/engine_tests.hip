@@ -7,6 +7,7 @@
 // explicit-frontier advance per schedule, filters, uniquify) are also written as JSON, and
 // tests/test_gpu_cpp_surface.py compares them with oracle/ -- the binary is not its own only judge.
 #include <gunrock/algorithms/algorithms.hxx>
+#include <gunrock/graph/reorder.hxx>
 #include <gunrock/hip/algorithms.hxx>
 
 #include <algorithm>
@@ -349,6 +350,170 @@ int main(int argc, char** argv) {
     hh = hits.to_host();
     for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_hits[v];
     if (!ok) { std::printf("FAIL settled hint ignored where it must be\n"); ++failures; }
+    ctx0->options() = saved;
+  }
+
+  // ---- round-3 engine extensions: select_range, with_bounds, hot_first -----------------------------
+  {
+    auto* ctx0 = mc->get_context(0);
+    const auto saved = ctx0->options();
+    // (1) operators::filter::select_range == sequence(0, n) + filter::predicated as a SET, with the
+    //     selection's degree sum as work hint, ascending runs, and the two side products
+    frontier_t picked;
+    hip::device_array_t<int> touched(hg.n);
+    touched.zero();
+    int* pt = touched.data();
+    const std::size_t bit_limit = ((std::size_t)hg.n / 64) * 64;
+    hip::device_array_t<unsigned long long> words(bit_limit / 64);
+    auto want_v = [] __host__ __device__(vertex_t const& v) -> bool { return v % 3 == 1; };
+    auto each = [pt] __device__(vertex_t const& v) { pt[v] += 1; };
+    auto bit = [] __device__(vertex_t const& v) -> bool { return v % 7 == 0; };
+    operators::filter::select_range(G, (std::size_t)hg.n, want_v, picked, *ctx0, each, bit, words.data(), bit_limit);
+    auto got = picked.to_host();
+    std::vector<int> expect;
+    unsigned long long expect_work = 0;
+    for (int v = 0; v < hg.n; ++v)
+      if (v % 3 == 1) { expect.push_back(v); expect_work += (unsigned long long)(hg.ap[v + 1] - hg.ap[v]); }
+    bool runs_ascend = true;  // inside every run of one 8192-id chunk
+    for (std::size_t i = 1; i < got.size(); ++i)
+      if (got[i] < got[i - 1] && got[i] / 8192 == got[i - 1] / 8192) runs_ascend = false;
+    auto sorted_got = got;
+    std::sort(sorted_got.begin(), sorted_got.end());
+    CHECK(sorted_got == expect && runs_ascend);
+    CHECK(picked.work_hint() == expect_work && picked.ascending());
+    auto th = touched.to_host();
+    CHECK(std::all_of(th.begin(), th.end(), [](int x) { return x == 1; }));  // `each`: once per id
+    auto wh = words.to_host();
+    bool bits_ok = true;
+    for (std::size_t v = 0; v < bit_limit; ++v) bits_ok &= (((wh[v / 64] >> (v % 64)) & 1ull) != 0) == (v % 7 == 0);
+    CHECK(bits_ok);
+    dump_array("select_range_output", sorted_got);
+    dump_array("select_range_work_hint", std::vector<long long>{(long long)picked.work_hint()});
+    // an ascending frontier is dealt across the tiles of the wide-level kernel: same calls, same set
+    {
+      ctx0->options().settled_min_work = 1;
+      hip::device_array_t<int> hits(hg.n);
+      hits.zero();
+      int* ph = hits.data();
+      auto count = [ph] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                            weight_t const& w) -> bool {
+        math::atomic::add(&ph[d], 1);
+        return (s + d) % 2 == 0;
+      };
+      operators::advance::settled_filter_t<vertex_t> none_named;
+      none_named.rebuild((std::size_t)hg.n, [] __device__(vertex_t) { return false; }, *ctx0);
+      frontier_t out_f;
+      hip::device_array_t<edge_t> seg;
+      CHECK(picked.ascending());
+      operators::advance::execute<operators::load_balance_t::block_mapped, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(
+          G, operators::advance::with_settled(count, none_named.view()), &picked, &out_f, seg, *mc);
+      std::vector<long long> want_calls(hg.n, 0);
+      std::multiset<int> want_kept;
+      for (int v : expect)
+        for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) {
+          want_calls[hg.aj[e]] += 1;
+          if ((v + hg.aj[e]) % 2 == 0) want_kept.insert(hg.aj[e]);
+        }
+      auto hh = hits.to_host();
+      auto oo = out_f.to_host();
+      std::multiset<int> got_kept(oo.begin(), oo.end());
+      bool ok = got_kept == want_kept;
+      for (int v = 0; v < hg.n; ++v) ok &= hh[v] == want_calls[v];
+#ifndef GRX_ADVANCE_LB_OVERRIDE
+      if (!ok) { std::printf("FAIL ascending frontier dealt across tiles\n"); ++failures; }
+#else
+      CHECK(ok);
+#endif
+    }
+    // (2) operators::advance::with_bounds: a min-relaxation with a 2-byte bound image gives the labels and
+    //     the improved set of the plain functor
+    {
+      ctx0->options().settled_min_work = 1;
+      const unsigned far = 1u << 30;
+      std::vector<unsigned> init(hg.n, far);
+      for (int v : fin_h) if (v >= 0) init[v] = (unsigned)(v % 50);
+      auto run = [&](bool bounded, std::vector<unsigned>& labels_out, std::multiset<int>& improved) {
+        auto d_label = upload(init);
+        auto d_source = upload(init);  // what a source hands on is read from a copy: one Jacobi round, the
+        unsigned* lab = d_label.data();  // same labels whatever order the engine relaxes in
+        const unsigned* from = d_source.data();
+        hip::device_array_t<unsigned short> bound16(hg.n);
+        unsigned short* b16 = bound16.data();
+        hip::for_each_index((std::size_t)hg.n, [lab, b16] __device__(std::size_t i) {
+          b16[i] = lab[i] >= 0xffffu ? (unsigned short)0xffffu : (unsigned short)lab[i];  // exact for small labels
+        }, ctx.stream());
+        auto relax = [lab, from] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                                     weight_t const& w) -> bool {
+          const unsigned through = from[s] + (unsigned)w;
+          return through < math::atomic::min(&lab[d], through);
+        };
+        auto cached = [from] __device__(vertex_t const& s, vertex_t const& d, edge_t const& e, weight_t const& w,
+                                        unsigned short const& b) -> bool {
+          return b != 0xffffu && from[s] + (unsigned)w >= (unsigned)b;
+        };
+        auto pred = [cached, b16] __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                             weight_t const& w) -> bool { return cached(s, d, e, w, b16[d]); };
+        frontier_t fin2, fout2;
+        for (int v : fin_h) fin2.push_back(v);
+        unsigned long long work = 0;
+        for (int v : fin_h) if (v >= 0) work += (unsigned long long)(hg.ap[v + 1] - hg.ap[v]);
+        fin2.set_work_hint(work);
+        hip::device_array_t<edge_t> seg;
+        constexpr auto lb = operators::load_balance_t::block_mapped;
+        if (bounded)
+          operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::vertices,
+                                      operators::advance_io_type_t::vertices>(
+              G, operators::advance::with_bounds<vertex_t>(relax, pred, cached, b16, (std::size_t)hg.n), &fin2,
+              &fout2, seg, *mc);
+        else
+          operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::vertices,
+                                      operators::advance_io_type_t::vertices>(G, relax, &fin2, &fout2, seg, *mc);
+        labels_out = d_label.to_host();
+        auto o = fout2.to_host();
+        improved = std::multiset<int>(o.begin(), o.end());
+      };
+      std::vector<unsigned> plain_labels, bounded_labels;
+      std::multiset<int> plain_out, bounded_out;
+      run(false, plain_labels, plain_out);
+      run(true, bounded_labels, bounded_out);
+      // the labels are a min over the same candidates whatever the order; the emitted multiset is not
+      // (which of several improvers of a vertex "wins" more than once depends on timing): compare sets
+      CHECK(plain_labels == bounded_labels);
+      CHECK(std::set<int>(plain_out.begin(), plain_out.end()) == std::set<int>(bounded_out.begin(), bounded_out.end()));
+      std::vector<long long> as_ll(bounded_labels.begin(), bounded_labels.end());
+      dump_array("with_bounds_initial_labels", std::vector<long long>(init.begin(), init.end()));
+      dump_array("with_bounds_labels", as_ll);
+    }
+    // (3) graph::build::hot_first: an isomorphic copy in descending degree order
+    {
+      unsigned long long max_deg = 0;
+      for (int v = 0; v < hg.n; ++v) max_deg = std::max<unsigned long long>(max_deg, hg.ap[v + 1] - hg.ap[v]);
+      auto R = graph::build::hot_first(G, *ctx0, max_deg);
+      auto ro = R.offsets.to_host();
+      auto rj = R.indices.to_host();
+      auto rx = R.values.to_host();
+      auto rank_of = R.rank_of.to_host();
+      auto vertex_of = R.vertex_of.to_host();
+      bool ok = ro[0] == 0 && ro[hg.n] == (int)hg.aj.size();
+      for (int r = 0; r < hg.n && ok; ++r) {
+        const int v = vertex_of[r];
+        ok &= rank_of[v] == r;
+        const int deg = ro[r + 1] - ro[r];
+        ok &= deg == hg.ap[v + 1] - hg.ap[v];
+        if (r) ok &= deg <= ro[r] - ro[r - 1];                                  // falling degrees
+        if (r && deg == ro[r] - ro[r - 1]) ok &= vertex_of[r - 1] < v;          // ties keep the input order
+        for (int k = 0; k < deg && ok; ++k)                                     // rows keep their edge order
+          ok &= rj[ro[r] + k] == rank_of[hg.aj[hg.ap[v] + k]] && rx[ro[r] + k] == hg.ax[hg.ap[v] + k];
+      }
+      CHECK(ok);
+      dump_array("hot_first_vertex_of", vertex_of);
+      dump_array("hot_first_offsets", ro);
+      dump_array("hot_first_indices", rj);
+    }
     ctx0->options() = saved;
   }
 

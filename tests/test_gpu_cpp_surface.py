@@ -102,4 +102,24 @@ def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
     assert d["transpose_result_indices"] == rows[order].tolist()
     assert d["transpose_result_offsets"] == np.concatenate(
         [[0], np.cumsum(np.bincount(tAj, minlength=len(tAp) - 1))]).tolist()
+    # round-3 engine extensions, checked HERE against plain numpy restatements of their contracts
+    n = len(Ap) - 1   # (the sort section above reused the name)
+    assert d["select_range_output"] == [v for v in range(n) if v % 3 == 1]
+    assert d["select_range_work_hint"] == [int(np.diff(Ap)[1::3].sum())]
+    init = np.array(d["with_bounds_initial_labels"], np.int64)       # one min-relaxation round from the frontier
+    want_lab = init.copy()
+    for s_ in frontier[frontier >= 0]:
+        for e in range(Ap[s_], Ap[s_ + 1]):
+            want_lab[Aj[e]] = min(want_lab[Aj[e]], init[s_] + int(Ax[e]))
+    # (sources hand on a read-only copy of their label: exactly one Jacobi round, order-independent)
+    assert d["with_bounds_labels"] == want_lab.tolist()
+    order = np.array(d["hot_first_vertex_of"], np.int64)
+    assert sorted(order.tolist()) == list(range(n))
+    deg = np.diff(Ap)
+    assert (np.diff(deg[order]) <= 0).all()                          # falling degrees
+    assert d["hot_first_offsets"] == np.concatenate([[0], np.cumsum(deg[order])]).tolist()
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    want_cols = np.concatenate([rank[Aj[Ap[v]:Ap[v + 1]]] for v in order]) if len(Aj) else np.zeros(0, np.int64)
+    assert d["hot_first_indices"] == want_cols.tolist()
     assert d["failures"] == [0]
