@@ -11,7 +11,7 @@ import collections, csv, glob, json, re, sys
 
 root = sys.argv[1]
 WANT = ("expand_settled", "expand_fused", "expand_ranked", "block_mapped_kernel", "chunk_kernel", "classify_hubs",
-        "rebuild", "gather_probe", "merge_path_kernel", "bucket_kernel", "thread_mapped", "wave_mapped")
+        "rebuild", "select_range", "gather_probe", "merge_path_kernel", "bucket_kernel", "thread_mapped", "wave_mapped")
 CHANNELS = 128
 
 
@@ -20,12 +20,13 @@ def short(name):
 
 
 def last_traversal(seq):
-    """seq: [(dispatch id, kernel name, payload)] in launch order -> the slice between the last two
-    reach_stats kernels (one traversal), operator kernels only."""
-    ends = [i for i, (_, n, _) in enumerate(seq) if "reach_stats" in n]
-    lo = ends[-2] + 1 if len(ends) >= 2 else 0
-    hi = ends[-1] + 1 if ends else len(seq)
-    return [x for x in seq[lo:hi] if any(w in x[1] for w in WANT)]
+    """seq: [(dispatch id, kernel name, payload, full name)] in launch order -> the last traversal:
+    from the last reset pass of a problem (index_kernel over `...problem_t<...>::reset()`'s lambda)
+    on, operator kernels only.  (Round 2 cut at reach_stats_kernel, which the default forms no longer
+    launch.)"""
+    starts = [i for i, x in enumerate(seq) if "problem_t<" in x[3] and "::reset()" in x[3]]
+    lo = starts[-1] if starts else 0
+    return [x[:3] for x in seq[lo:] if any(w in x[1] for w in WANT)]
 
 
 def counters(sub):
@@ -35,19 +36,20 @@ def counters(sub):
     if not fs:
         return []
     vals = collections.OrderedDict()
-    names = {}
+    names, full = {}, {}
     for r in csv.DictReader(open(fs[-1])):
         d = int(r["Dispatch_Id"])
         vals.setdefault(d, {})
         vals[d][r["Counter_Name"]] = vals[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         names[d] = short(r["Kernel_Name"])
-    return last_traversal([(d, names[d], vals[d]) for d in sorted(vals)])
+        full[d] = r["Kernel_Name"]
+    return last_traversal([(d, names[d], vals[d], full[d]) for d in sorted(vals)])
 
 
 trace = sorted(glob.glob(f"{root}/trace/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 seq = last_traversal([(int(r["Dispatch_Id"]), short(r["Kernel_Name"]),
-                       (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows])
+                       (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"]) for r in rows])
 passes = {sub: counters(sub) for sub in ("rdreq", "wrreq", "l2")}
 # SSSP's iteration count is timing dependent (which improvement of a vertex lands first), so a
 # pass may run one more or one fewer narrow iteration at the END: keep the common prefix

@@ -6,10 +6,11 @@ path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("<")[0].split("(")[0].split("::")[-1] for r in rows]
-# last traversal = after the last reset (for_each_index... of the depth fill): find last 'reach_stats'
-ends = [i for i, n in enumerate(names) if "reach_stats" in n]
-lo = ends[-2] + 1 if len(ends) >= 2 else 0
-hi = ends[-1] + 1 if ends else len(rows)
+# last traversal = from the last reset pass of a problem (index_kernel over `...problem_t<...>::reset()`'s
+# lambda) on; the default forms no longer end with a reach_stats_kernel (round 3)
+starts = [i for i, r in enumerate(rows) if "problem_t<" in r["Kernel_Name"] and "::reset()" in r["Kernel_Name"]]
+lo = starts[-1] if starts else 0
+hi = len(rows)
 tot = 0.0
 for r, n in zip(rows[lo:hi], names[lo:hi]):
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
