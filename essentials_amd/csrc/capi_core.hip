@@ -94,6 +94,7 @@ int essentials_amd::ensure_can_pull(grx_context_s* ctx, grx_graph_s* g) {
 }
 
 grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
+  std::lock_guard<std::mutex> lock(g->hot_mutex);
   if (g->in_edges)
     return nullptr;  // attached after the copy was made: the copy has no transpose
   if (g->hot) {
@@ -147,6 +148,7 @@ int grx_graph_hot_first(grx_context_t ctx, grx_graph_t g, int enable) {
     return invalid("grx_graph_hot_first: NULL argument");
   return guarded([&] {
     if (!enable) {
+      std::lock_guard<std::mutex> lock(g->hot_mutex);
       g->hot_first = 0;
       g->hot.reset();
       g->hot_vertex_of = hip::device_array_t<int32_t>();

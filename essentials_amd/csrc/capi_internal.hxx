@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <climits>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include <string>
 
@@ -66,7 +67,9 @@ struct grx_context_s {
   // the size class of the frontier the next grx_partitioned_step expands -- and the settled bitmap
   // its wide BFS supersteps rebuild (operators/settled.hxx)
   long long superstep_finds_hint = -1;
+  long long superstep_found_so_far = 0;  // all ranks, all earlier supersteps of the run
   gunrock::operators::advance::settled_filter_t<int32_t> superstep_settled;
+  gunrock::hip::device_array_t<unsigned short> superstep_bound16;  // SSSP: 2-byte distance bounds
   gunrock::gcuda::standard_context_t& single() { return *mc->get_context(0); }
 };
 
@@ -116,6 +119,7 @@ struct grx_graph_s {
   // labels are delivered in the caller's numbering.  -1: automatic (GRX_HOT_FIRST, size), 0: off,
   // 1: on (grx_graph_hot_first).
   int hot_first = -1;
+  std::mutex hot_mutex;  // the copy is built on first use: handles may be shared between host threads
   std::unique_ptr<grx_graph_s> hot;
   gunrock::hip::device_array_t<int32_t> hot_vertex_of;  // device: caller's id of a renumbered vertex
   std::vector<int32_t> hot_rank_of;                     // host: renumbered id of a caller's vertex

@@ -526,9 +526,48 @@ int grx_partitioned_step(grx_context_t ctx, grx_graph_t local, const grx_options
           return false;
         return math::atomic::exch(&sent[dst], rnd) != rnd;
       };
-      operators::advance::block_mapped::enqueue_packed(G, relax, d_frontier, bound, count_dev,
-                                                       (unsigned long long)local->nnz, d_scratch,
-                                                       (std::size_t)scratch_capacity, sc);
+      // wide supersteps once a quarter of the vertices have been found (the hubs are reached): the
+      // single-GPU search's 2-byte bound image in front of the distances (operators::advance::
+      // with_bounds; clients.hxx::sssp_enactor_t) -- bounds of the replica as it stands now
+      bool wide = false;
+      if (sc.options().settled_filter && ctx->superstep_finds_hint >= (long long)sc.options().fused_min_slots &&
+          4 * ctx->superstep_found_so_far >= (long long)local->n_rows) {
+        auto ordered = [] __host__ __device__(float x) -> unsigned {
+          unsigned b;
+          memcpy(&b, &x, 4);
+          return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+        };
+        if (ctx->superstep_bound16.size() < (std::size_t)local->n_rows)
+          ctx->superstep_bound16.resize((std::size_t)local->n_rows);
+        unsigned short* bound16 = ctx->superstep_bound16.data();
+        const float* dist_now = dist;
+        hip::for_each_index(
+            (std::size_t)local->n_rows,
+            [dist_now, bound16, ordered] __device__(std::size_t i) {
+              const unsigned bits = ordered(dist_now[i]);
+              const unsigned up = (bits >> 16) + ((bits & 0xffffu) ? 1u : 0u);
+              bound16[i] = (unsigned short)(up > 0xffffu ? 0xffffu : up);
+            },
+            sc.stream());
+        auto cached = [dist, ordered] __device__(vertex_t const& src, vertex_t const& dst, edge_t const& e,
+                                                 weight_t const& w, unsigned short const& b) -> bool {
+          const unsigned limit = (unsigned)b;
+          return limit != 0xffffu && ordered(dist[src] + w) >= (limit << 16);
+        };
+        const unsigned short* bounds = bound16;
+        auto not_shorter = [cached, bounds] __device__(vertex_t const& src, vertex_t const& dst, edge_t const& e,
+                                                       weight_t const& w) -> bool {
+          return cached(src, dst, e, w, bounds[dst]);
+        };
+        wide = operators::advance::block_mapped::enqueue_packed_settled(
+            G, operators::advance::with_bounds<vertex_t>(relax, not_shorter, cached, bounds, (std::size_t)local->n_rows),
+            d_frontier, bound, count_dev, (unsigned long long)local->nnz, d_scratch, (std::size_t)scratch_capacity,
+            sc);
+      }
+      if (!wide)
+        operators::advance::block_mapped::enqueue_packed(G, relax, d_frontier, bound, count_dev,
+                                                         (unsigned long long)local->nnz, d_scratch,
+                                                         (std::size_t)scratch_capacity, sc);
     }
     // 3. pack the finds (their number is counters[C_OUT], still on the device; C_SELECT is zero:
     //    every hand-off clears it)

@@ -212,6 +212,7 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* calle
   if (const char* e = std::getenv("GRX_PARTITIONED_FAIL_AT"))
     std::sscanf(e, "%d:%d", &fail_rank, &fail_round);
   p.ctx->superstep_finds_hint = -1;
+  p.ctx->superstep_found_so_far = 0;
   for (;;) {
     attempt([&] {
       if (rank == fail_rank && rounds == fail_round) {
@@ -293,6 +294,7 @@ int run_as(grx_partitioned_s& p, int32_t edge_op, int32_t source, label_t* calle
     }
     found_total += sum;
     p.ctx->superstep_finds_hint = sum;  // what the next step's owned frontiers add up to, at most
+    p.ctx->superstep_found_so_far = found_total;
     recv_prev = recv;
     slot_prev = slot;
     fmt_prev = fmt;
