@@ -225,6 +225,8 @@ int expand_as(grx_context_t ctx, grx_graph_t local, const grx_options& o, int32_
 
 extern "C" {
 
+}  // extern "C"
+
 namespace {
 /// Rank `rank`'s slice of `full` (rows outside [lo, hi) empty, global ids).
 std::unique_ptr<grx_graph_s> slice_of(grx_graph_s* full, int rank, int world, int32_t& lo, int32_t& hi) {
@@ -264,6 +266,8 @@ std::unique_ptr<grx_graph_s> slice_of(grx_graph_s* full, int rank, int world, in
   return g;
 }
 }  // namespace
+
+extern "C" {
 
 int grx_graph_partition(grx_graph_t full, int rank, int world, grx_graph_t* out,
                         int32_t* row_begin, int32_t* row_end) {

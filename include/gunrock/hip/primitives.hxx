@@ -141,8 +141,8 @@ enum class sort_order_t { ascending, descending };
 template <typename key_t>
 std::size_t radix_sort_temp_bytes(std::size_t n) {
   std::size_t bytes = 0;
-  rocprim::radix_sort_keys(nullptr, bytes, (key_t*)nullptr, (key_t*)nullptr, n, 0,
-                           8 * sizeof(key_t), nullptr);
+  GRX_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (key_t*)nullptr, (key_t*)nullptr, n, 0,
+                                         8 * sizeof(key_t), nullptr));
   return bytes;
 }
 
@@ -163,7 +163,7 @@ void radix_sort_keys(void* temp, std::size_t temp_bytes, const key_t* keys_in, k
 template <typename in_it, typename out_it, typename T>
 std::size_t exclusive_sum_temp_bytes(in_it in, out_it out, T init, std::size_t n) {
   std::size_t bytes = 0;
-  rocprim::exclusive_scan(nullptr, bytes, in, out, init, n, rocprim::plus<T>(), nullptr);
+  GRX_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, init, n, rocprim::plus<T>(), nullptr));
   return bytes;
 }
 
