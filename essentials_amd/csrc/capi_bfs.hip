@@ -59,6 +59,8 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
       } else {
         clients::bfs_enactor_t<problem_type, lb> enactor(&problem, ctx->mc, props);
         enactor.max_iterations = o.max_iterations;
+        if (const char* e = std::getenv("GRX_BFS_MARK"))
+          enactor.mark_without_claim = std::atoi(e) != 0;
         ms = enactor.enact();
         iterations = enactor.iteration;
       }

@@ -185,9 +185,11 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
   void finalize(gcuda::multi_context_t&) override { this->get_problem()->deliver(); }
 
   /// One level.  `visit` discovers, `has_depth` is its pure "already discovered" test,
-  /// `found_now(v)` says that THIS level discovered v (asked after the level).
-  template <typename visit_t, typename has_depth_t, typename found_t>
-  void expand(visit_t visit, has_depth_t has_depth, found_t found_now, gcuda::multi_context_t& context) {
+  /// `found_now(v)` says that THIS level discovered v (asked after the level), `mark` is visit for a
+  /// level whose output nobody reads: it labels an unlabelled destination and returns nothing of use.
+  template <typename visit_t, typename has_depth_t, typename found_t, typename mark_t>
+  void expand(visit_t visit, has_depth_t has_depth, found_t found_now, mark_t mark,
+              gcuda::multi_context_t& context) {
     auto E = this->get_enactor();
     auto G = this->get_problem()->get_graph();
     // wide levels (block_mapped's fused form): every vertex that has a depth is settled -- visit()
@@ -208,11 +210,25 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         // one pass over them builds the next frontier in ascending runs with its degree sum
         // (operators::filter::select_range; the graph's vertices without edges are skipped when a
         // hot-first numbering put them last)
+        // Nobody reads this level's output, so nobody needs to know WHO reached a vertex first: every
+        // arrival that finds it unlabelled writes the same depth.  `mark` is a plain conditional
+        // store where visit() is a fresh look + a read-modify-write at the memory side (27 G/s on this
+        // part whatever the scope, tools/scatter_probe.hip) whose round trips the surviving edges'
+        // wavefronts wait for: level 1 of RMAT-22 spent 122 of its 396 us in them, 70 of 346 us with
+        // the store (calling a store-only functor for the edges the predicate has just passed, without
+        // the conditional's load, was measured too: 343 us -- not kept).
+        const bool idempotent = ctx->options().settled_filter && mark_without_claim;
         ctx->options().defer_sync_of_none_output = true;  // select_range below is its hand-off
-        operators::advance::execute<lb, operators::advance_direction_t::forward,
-                                    operators::advance_io_type_t::vertices,
-                                    operators::advance_io_type_t::none>(
-            G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
+        if (idempotent)
+          operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::vertices,
+                                      operators::advance_io_type_t::none>(
+              G, E, operators::advance::with_settled(mark, settled.view(), has_depth), context);
+        else
+          operators::advance::execute<lb, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::vertices,
+                                      operators::advance_io_type_t::none>(
+              G, E, operators::advance::with_settled(visit, settled.view(), has_depth), context);
         ctx->options().defer_sync_of_none_output = false;
         const std::size_t n_scan = G.properties.leading_connected
                                        ? (std::size_t)G.properties.leading_connected
@@ -266,7 +282,14 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
       auto found_byte = [words, level] __device__(vertex_t const& v) -> bool {
         return ((words[(unsigned)v >> 2] >> (((unsigned)v & 3u) * 8u)) & 0xFFu) == level;
       };
-      expand(visit_byte, has_byte, found_byte, context);
+      unsigned char* bytes = reinterpret_cast<unsigned char*>(words);  // byte v of the array (little endian)
+      auto mark_byte = [bytes, level] __device__(vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                                 weight_t const& weight) -> bool {
+        if (bytes[(unsigned)dst] == 0xFFu)
+          bytes[(unsigned)dst] = (unsigned char)level;  // a 1-byte store: no neighbour's byte is touched
+        return false;
+      };
+      expand(visit_byte, has_byte, found_byte, mark_byte, context);
       return;
     }
     auto visit = [depth, next_level] __host__ __device__(vertex_t const& src, vertex_t const& dst,
@@ -283,9 +306,16 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
     auto found_now = [depth, next_level] __device__(vertex_t const& v) -> bool {
       return depth[v] == next_level;
     };
-    expand(visit, has_depth, found_now, context);
+    auto mark = [depth, next_level] __device__(vertex_t const& src, vertex_t const& dst, edge_t const& edge,
+                                               weight_t const& weight) -> bool {
+      if (depth[dst] == std::numeric_limits<vertex_t>::max())
+        depth[dst] = next_level;
+      return false;
+    };
+    expand(visit, has_depth, found_now, mark, context);
   }
   operators::advance::settled_filter_t<vertex_t> settled;
+  bool mark_without_claim = true;  // label-scan levels label with a plain store (GRX_BFS_MARK=0: the claim)
 };
 
 // ---------------------------------------------------------------------------
