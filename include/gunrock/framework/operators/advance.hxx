@@ -173,6 +173,13 @@ unsigned long long degree_sum(graph_t& G, const vertex_t* input, std::size_t n_i
   return fetch_counters(ctx)[k::C_WORK];
 }
 
+/// How an ascending frontier is dealt across the tiles of the wide-level kernel (advance_kernels.hxx):
+/// 2 = across the tiles, workgroup-major; 1 = across the tiles, wave-major (GRX_DEALT_MODE, experiments).
+inline int dealt_mode() {
+  static const int mode = std::getenv("GRX_DEALT_MODE") ? std::atoi(std::getenv("GRX_DEALT_MODE")) : 2;
+  return mode;
+}
+
 inline unsigned long long saturating_mul(unsigned long long a, unsigned long long b) {
   if (a == 0 || b == 0)
     return 0;
@@ -376,7 +383,8 @@ void execute(graph_t& G,
           }
           kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
               G, op, input.data(), n_in, out_ptr, capacity, counters, chunks, chunk_capacity, mask, cursors,
-              (const unsigned long long*)nullptr, input_type == advance_io_type_t::vertices && input.ascending());
+              (const unsigned long long*)nullptr,
+              input_type == advance_io_type_t::vertices && input.ascending() ? detail::dealt_mode() : 0);
           GRX_HIP_CHECK(hipGetLastError());
           expanded = true;
         }
@@ -518,7 +526,7 @@ bool enqueue_packed_settled(graph_t& G,
                              chunk_edges, mask, cursors, counters);
   kernel<<<(unsigned)context.compute_units(), k::SET_BLOCK, lds, context.stream()>>>(
       G, op, input, n_in_bound, output, capacity, counters, chunks, chunk_capacity, mask, cursors, n_in_device,
-      false);
+      0);
   GRX_HIP_CHECK(hipGetLastError());
   return true;
 }

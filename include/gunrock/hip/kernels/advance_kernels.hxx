@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(SET_BLOCK)
                           unsigned long long chunk_capacity,
                           const unsigned long long* __restrict__ hub_mask,
                           unsigned long long* __restrict__ claim_cursors,
-                          const unsigned long long* n_in_device = nullptr, bool dealt = false) {
+                          const unsigned long long* n_in_device = nullptr, int dealt = 0) {
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   using weight_t = typename graph_t::weight_type;
   using pending_t = pending_edge_t<vertex_t, edge_t>;
@@ -1012,7 +1012,11 @@ __global__ void __launch_bounds__(SET_BLOCK)
       }
     }
   };
-  unsigned long long tile = (unsigned long long)wave * gridDim.x + blockIdx.x;
+  // dealt == 2: the sixteen wavefronts of a workgroup take CONSECUTIVE tiles, i.e. consecutive slots of
+  // every stratum -- their 4-byte reads of the frontier, the hub mask and the row offsets fall into
+  // lines the CU already holds (wave-major numbering spreads neighbouring tiles over all CUs and XCDs)
+  unsigned long long tile = dealt == 2 ? (unsigned long long)blockIdx.x * SET_WAVES + wave
+                                       : (unsigned long long)wave * gridDim.x + blockIdx.x;
   vertex_t v, v1;
   edge_t first, last, first1, last1;
   fetch_slot(tile, v, first, last);
