@@ -15,6 +15,7 @@
  */
 #pragma once
 
+#include <atomic>
 #include <memory>
 #include <vector>
 
@@ -65,6 +66,14 @@ struct enactor_properties_t {
   bool self_manage_frontiers{false};
 };
 
+namespace detail {
+/// One counter for every enactor type of the process.
+inline unsigned long long next_enactor_id() {
+  static std::atomic<unsigned long long> last{0};
+  return ++last;
+}
+}  // namespace detail
+
 template <typename algorithm_problem_t,
           frontier::frontier_kind_t frontier_kind = frontier::frontier_kind_t::vertex_frontier,
           frontier::frontier_view_t frontier_view = frontier::frontier_view_t::vector>
@@ -82,6 +91,8 @@ struct enactor_t {
   frontier_t* inactive_frontier;
   int buffer_selector;
   int iteration;
+  /// Never reused within the process (operators key per-run state by it, not by the enactor's address).
+  const unsigned long long unique_id = detail::next_enactor_id();
 
   enactor_t(const enactor_t&) = delete;
   enactor_t& operator=(const enactor_t&) = delete;

@@ -21,6 +21,7 @@
  */
 #pragma once
 
+#include <gunrock/framework/operators/by_destination.hxx>
 #include <gunrock/framework/operators/configs.hxx>
 #include <gunrock/hip/context.hxx>
 #include <gunrock/hip/kernels/advance_kernels.hxx>
@@ -958,6 +959,21 @@ void execute(graph_t& G,
                             "Advance type not supported.");
   auto& ctx = *context.get_context(0);
   constexpr load_balance_t schedule = GRX_LB_EFFECTIVE(lb);
+  // every edge of the graph, nothing written: the order of the calls is the engine's choice, and
+  // grouped by destination the functor's atomics combine (operators/by_destination.hxx)
+  if constexpr (input_type == advance_io_type_t::graph && output_type == advance_io_type_t::none) {
+    if (const void* items =
+            by_destination::prepared(G, ctx.workspace().by_destination().current_run, ctx)) {
+      detail::clocked_t clock(ctx);
+      by_destination::enqueue(G, items, op, ctx);
+      if (ctx.options().defer_sync_of_none_output)
+        return;
+      clock.stop();
+      detail::fetch_counters(ctx);  // waits for the kernel
+      ctx.kernel_clock().collect();
+      return;
+    }
+  }
   // deterministic output positions exist only for merge_path / thread_mapped / block_mapped
   const bool holes = ctx.options().holes_layout && output_type != advance_io_type_t::none;
 
@@ -1001,9 +1017,13 @@ void execute(graph_t& G,
              operator_type op,
              gcuda::multi_context_t& context,
              bool swap_buffers = true) {
+  if constexpr (input_type == advance_io_type_t::graph && output_type == advance_io_type_t::none)
+    context.get_context(0)->workspace().by_destination().current_run = E->unique_id;
   execute<lb, direction, input_type, output_type>(G, op, E->get_input_frontier(),
                                                   E->get_output_frontier(),
                                                   E->scanned_work_domain, context);
+  if constexpr (input_type == advance_io_type_t::graph && output_type == advance_io_type_t::none)
+    context.get_context(0)->workspace().by_destination().current_run = 0;
   if (swap_buffers && (output_type != advance_io_type_t::none))
     E->swap_frontier_buffers();
 }

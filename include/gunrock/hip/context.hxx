@@ -150,6 +150,23 @@ class workspace_t {
     return &graphs_.back();
   }
 
+  /// The edges of ONE graph ordered by destination (operators/by_destination.hxx), kept between
+  /// operator calls.  Identified by the addresses AND a 64-bit fingerprint of the three CSR
+  /// arrays' contents: memory released and reused for another graph never matches.
+  struct by_destination_t {
+    const void* offsets = nullptr;
+    const void* indices = nullptr;
+    const void* values = nullptr;
+    std::size_t vertices = 0, edges = 0;
+    unsigned long long fingerprint = 0;
+    unsigned long long checked_for = 0;  ///< enactor (bsp.hxx unique_id) the fingerprint was last compared in
+    unsigned long long current_run = 0;  ///< enactor whose advance is being dispatched (0: none)
+    unsigned calls = 0;                  ///< whole-graph advances without an output seen on this graph
+    bool built = false;
+    hip::buffer_t<unsigned char> items;  ///< [edges] {source, destination, edge, weight}
+  };
+  by_destination_t& by_destination() { return by_destination_; }
+
  private:
   hip::buffer_t<unsigned long long> counters_;
   hip::pinned_t<unsigned long long> mirror_{n_counters};
@@ -158,6 +175,7 @@ class workspace_t {
   hip::buffer_t<unsigned char> scratch_;
   hip::buffer_t<unsigned char> queue_;
   std::vector<graph_facts_t> graphs_;
+  by_destination_t by_destination_;
 };
 
 /// Run-time switches of the operators (per context).
@@ -201,6 +219,10 @@ struct operator_options_t {
   /// at once on the same stream -- operators::filter::select_range): it only enqueues; the next
   /// operator's hand-off reports its overflow flags and closes its kernel-time interval.
   bool defer_sync_of_none_output = false;
+  /// A whole-graph advance WITHOUT an output (advance_io_type_t::graph -> none: `pr.hxx`'s push)
+  /// on a graph of at least this many edges walks the edges grouped by DESTINATION from its second
+  /// call on the same graph on (operators/by_destination.hxx); 0 = never (env GRX_BY_DESTINATION).
+  unsigned long long by_destination_min_edges = 1ull << 20;
   /// Event-time the advance expansion kernels (two events per operator call).
   bool time_kernels = false;
 };
@@ -319,6 +341,8 @@ class standard_context_t {
       options_.settled_min_work = (unsigned long long)std::atoll(e);
     if (const char* e = std::getenv("GRX_LABEL_SCAN_MIN_WORK"))
       options_.label_scan_min_work = (unsigned long long)std::atoll(e);
+    if (const char* e = std::getenv("GRX_BY_DESTINATION"))
+      options_.by_destination_min_edges = (unsigned long long)std::atoll(e);  // 0: never, 1: always
     if (const char* e = std::getenv("GRX_CHUNK_QUEUE_LIMIT"))
       options_.chunk_queue_limit = (unsigned long long)std::atoll(e);
     GRX_HIP_CHECK(hipEventCreateWithFlags(&event_, hipEventDisableTiming));

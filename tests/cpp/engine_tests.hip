@@ -560,6 +560,121 @@ int main(int argc, char** argv) {
     CHECK(ok);
   }
 
+  // ---- whole-graph advance without an output, walked by destination (operators/by_destination.hxx)
+  {
+    using problem_type = toy_problem_t<graph_t>;
+    auto* ctx0 = mc->get_context(0);
+    const auto saved = ctx0->options();
+    ctx0->options().by_destination_min_edges = 1;  // this small graph too
+    const std::size_t nnz = hg.aj.size();
+    hip::device_array_t<float> sums(hg.n);
+    hip::device_array_t<int> calls(nnz);
+    hip::device_array_t<int> wrong(1);
+    float* ps = sums.data();
+    int* pc = calls.data();
+    int* pw = wrong.data();
+    // pr.hxx's shape: one float atomic add per edge into the destination's word; every call also
+    // proves it carries ITS edge's source / destination / weight and counts itself
+    auto spread = [G, ps, pc, pw] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                                       weight_t const& w) -> bool {
+      if (G.get_destination_vertex(e) != d || G.get_edge_weight(e) != w || e < G.get_starting_edge(s) ||
+          e >= G.get_starting_edge(s) + G.get_number_of_neighbors(s))
+        math::atomic::add(pw, 1);
+      math::atomic::add(pc + e, 1);
+      math::atomic::add(ps + d, w * (float)(1 + s % 3));   // small integers: float sums are exact
+      return false;
+    };
+    std::vector<float> want(hg.n, 0.0f);
+    for (int v = 0; v < hg.n; ++v)
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) want[hg.aj[e]] += hg.ax[e] * (float)(1 + v % 3);
+    auto& cache = ctx0->workspace().by_destination();
+    for (int run = 0; run < 2; ++run) {        // two enactors: the second finds the list built
+      problem_type P(G, mc);
+      toy_enactor_t<problem_type> E(&P, mc);
+      for (int call = 0; call < 3; ++call) {   // row by row, then sorted (built on the second call)
+        sums.zero(); calls.zero(); wrong.zero();
+        operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                    operators::advance_io_type_t::graph,
+                                    operators::advance_io_type_t::none>(G, &E, spread, *mc);
+        CHECK(cache.built == (run > 0 || call > 0));
+        CHECK(wrong.to_host()[0] == 0);
+        auto hc = calls.to_host();
+        CHECK(std::all_of(hc.begin(), hc.end(), [](int c) { return c == 1; }));  // once per edge
+        CHECK(sums.to_host() == want);
+      }
+    }
+    // the same addresses with other contents are another graph: the remembered list is dropped
+    std::vector<float> ax2 = hg.ax;
+    for (std::size_t e = 0; e < nnz; e += 3) ax2[e] += 1.0f;
+    auto d_ax_saved = upload(hg.ax);
+    GRX_HIP_CHECK(hipMemcpy((void*)G.get_nonzero_values(), ax2.data(), nnz * sizeof(float), hipMemcpyHostToDevice));
+    for (int v = 0; v < hg.n; ++v) want[v] = 0.0f;
+    for (int v = 0; v < hg.n; ++v)
+      for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) want[hg.aj[e]] += ax2[e] * (float)(1 + v % 3);
+    {
+      problem_type P(G, mc);
+      toy_enactor_t<problem_type> E(&P, mc);
+      for (int call = 0; call < 3; ++call) {
+        sums.zero(); calls.zero(); wrong.zero();
+        operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                    operators::advance_io_type_t::graph,
+                                    operators::advance_io_type_t::none>(G, &E, spread, *mc);
+        CHECK(cache.built == (call > 0));
+        CHECK(wrong.to_host()[0] == 0);
+        CHECK(sums.to_host() == want);
+      }
+    }
+    GRX_HIP_CHECK(hipMemcpy((void*)G.get_nonzero_values(), hg.ax.data(), nnz * sizeof(float), hipMemcpyHostToDevice));
+    {
+      std::vector<long long> as_int(want.begin(), want.end());
+      dump_array("by_destination_sums_reweighted", as_int);
+    }
+    // math::atomic::add on floats combines runs of neighbouring lanes with the same address: the
+    // totals are those of one add per lane, and the values returned for one word are the word's
+    // values in ONE order of the adds (all ones added: 0, 1, 2, ... each exactly once)
+    const int n_words = 97, n_lanes = 64 * 40;
+    hip::device_array_t<float> words(n_words), olds(n_lanes);
+    words.zero();
+    float* pwords = words.data();
+    float* polds = olds.data();
+    auto pattern = [] __host__ __device__(int i) -> int {
+      const int wave = i / 64, lane = i % 64;
+      switch (wave % 5) {
+        case 0: return 0;                       // the whole wave one word
+        case 1: return lane / 7;                // runs of 7
+        case 2: return lane;                    // no runs
+        case 3: return (lane / 3) % 2;          // the same two words again and again, runs of 3
+        default: return 50 + (lane * lane) / 97; // runs of falling length
+      }
+    };
+    frontier_t lanes;
+    lanes.sequence(0, (std::size_t)n_lanes, ctx.stream());
+    operators::parallel_for::execute<operators::parallel_for_each_t::element>(
+        lanes,
+        [pwords, polds, pattern] __device__(vertex_t const& i) {
+          if (i % 11 == 5) { polds[i] = -1.0f; return; }  // holes in the wave break runs
+          polds[i] = math::atomic::add(pwords + pattern(i), 1.0f);
+        },
+        *mc);
+    ctx.synchronize();
+    auto hw = words.to_host();
+    auto ho = olds.to_host();
+    std::vector<std::vector<float>> seen(n_words);
+    std::vector<float> count(n_words, 0.0f);
+    for (int i = 0; i < n_lanes; ++i) {
+      if (i % 11 == 5) continue;
+      count[pattern(i)] += 1.0f;
+      seen[pattern(i)].push_back(ho[i]);
+    }
+    bool ok = hw == count;
+    for (int wd = 0; wd < n_words && ok; ++wd) {
+      std::sort(seen[wd].begin(), seen[wd].end());
+      for (std::size_t r = 0; r < seen[wd].size() && ok; ++r) ok &= seen[wd][r] == (float)r;
+    }
+    CHECK(ok);
+    ctx0->options() = saved;
+  }
+
   // ---- enactor overloads: which frontier is active afterwards ------------------------------
   {
     using problem_type = toy_problem_t<graph_t>;

@@ -122,4 +122,11 @@ def test_cpp_operator_results_against_the_oracle(tmp_path, oracle):
     rank[order] = np.arange(n)
     want_cols = np.concatenate([rank[Aj[Ap[v]:Ap[v + 1]]] for v in order]) if len(Aj) else np.zeros(0, np.int64)
     assert d["hot_first_indices"] == want_cols.tolist()
+    # whole-graph advance walked by destination, after the weights were changed in place (every third
+    # edge + 1): the sums per destination of w * (1 + source % 3), recomputed here from the arrays
+    Ax2 = Ax.astype(np.float64).copy()
+    Ax2[::3] += 1.0
+    srcs = np.repeat(np.arange(n), np.diff(Ap))
+    want_sums = np.bincount(Aj, weights=Ax2 * (1 + srcs % 3), minlength=n)
+    assert d["by_destination_sums_reweighted"] == want_sums.astype(np.int64).tolist()
     assert d["failures"] == [0]

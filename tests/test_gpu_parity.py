@@ -170,6 +170,37 @@ def test_pagerank_against_restatement(ea, ctx, oracle, lb):
         assert abs(st.iterations - it) <= 1
 
 
+@pytest.mark.parametrize("lb", ["block_mapped", "merge_path"])
+def test_pagerank_push_walked_by_destination(ea, oracle, monkeypatch, lb):
+    """pr.hxx's push (a whole-graph advance without an output) walks the edges grouped by destination
+    from its second iteration on, float adds of neighbouring lanes combined (operators/
+    by_destination.hxx): same ranks as the restatement and as the row-by-row walk, on small graphs
+    (forced), on one above the default threshold, and again from the remembered list."""
+    for scale, ef, sym, force in ((10, 8, False, True), (12, 8, True, True), (17, 16, False, False)):
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, 3, 5, sym)
+        want, it = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+        results = {}
+        for mode in ("0", "1" if force else None):
+            if mode is None:
+                monkeypatch.delenv("GRX_BY_DESTINATION", raising=False)   # the default: >= 2^20 edges
+            else:
+                monkeypatch.setenv("GRX_BY_DESTINATION", mode)
+            c = ea.Context(0)                                             # reads the switch
+            G = ea.Graph.from_host_csr(Ap, Aj, Ax)
+            for again in range(2):                                        # second run: list remembered
+                p, st = ea.pagerank(c, G, 0.85, 1e-6, options=ea.Options(load_balance=ea.LoadBalance[lb]))
+                p = host(p)
+                assert abs(float(p.sum()) - 1.0) < 1e-3
+                assert np.abs(p - want).max() < 5e-6, (scale, lb, mode, again, np.abs(p - want).max())
+                assert abs(st.iterations - it) <= 1
+            results[mode] = p
+            G.close()
+            c.close()
+        a, b = results.values()
+        assert np.abs(a - b).max() < 5e-6
+    monkeypatch.delenv("GRX_BY_DESTINATION", raising=False)
+
+
 def test_pagerank_pull_matches_push_and_restatement(ea, ctx, oracle):
     """The pull form (sums per destination over in-edges, no atomics; new relative to pr.hxx)
     converges to the same ranks as the push scatter and the oracle's restatement; directed graphs

@@ -59,6 +59,23 @@ def test_reference_pr_header(refc, oracle):
     assert np.abs(p.cpu().numpy() - want).max() < 5e-6   # parity unpinned in the reference
 
 
+def test_reference_pr_header_walked_by_destination(refc, oracle, monkeypatch):
+    """The unchanged pr.hxx with its whole-graph advance walked by destination from the second
+    iteration on (forced on the small graph; the default from 2^20 edges): same ranks."""
+    import torch
+    for scale, ef, force in ((11, 8, True), (17, 16, False)):
+        if force:
+            monkeypatch.setenv("GRX_BY_DESTINATION", "1")
+        else:
+            monkeypatch.delenv("GRX_BY_DESTINATION", raising=False)
+        n, Ap, Aj, Ax = oracle.rmat_csr(scale, ef, 3, 0, False)
+        p = torch.empty(n, dtype=torch.float32, device="cuda")
+        refc.pr(dev(Ap), dev(Aj), dev(Ax), 0.85, 1e-6, p)
+        want, _ = oracle.pagerank(Ap, Aj, Ax, 0.85, 1e-6)
+        assert np.abs(p.cpu().numpy() - want).max() < 5e-6, scale
+    monkeypatch.delenv("GRX_BY_DESTINATION", raising=False)
+
+
 def test_reference_bfs_header_rmat20(refc, oracle):
     """Same engine, reference client: a graph big enough for hubs, chunks and several levels."""
     import torch
