@@ -52,6 +52,10 @@ def attribute(name):
         client = "pagerank_pull"
     if k == "gather_probe_kernel":
         client = "probe"
+    if "by_destination" in name:   # the destination-sorted walk and its one-time build / fingerprint
+        k = "by_destination_" + (re.search(r"by_destination::k::(\w+)", name) or m).group(1)
+        if client == "-":
+            client = "pagerank_push" if k.endswith("expand_kernel") else "pagerank_setup"
     return k, client
 
 
@@ -83,6 +87,12 @@ def attribute_all(names):
             for j in run:
                 if out[j][1] == "sssp":
                     out[j] = (out[j][0], "sssp_two_pass")
+        # the push PageRank run in which the edge list is sorted by destination (one iteration row by
+        # row, then the build): not what an iteration costs from then on
+        if any(out[j][0] == "by_destination_pack_kernel" for j in run):
+            for j in run:
+                if out[j][1] == "pagerank_push":
+                    out[j] = (out[j][0], "pagerank_push_first_run")
     return out
 
 
