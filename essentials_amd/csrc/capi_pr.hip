@@ -35,6 +35,8 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
       if (problem.pull) {
         clients::pr_pull_enactor_t<problem_type> enactor(&problem, ctx->mc, props);
         enactor.max_iterations = o.max_iterations;
+        if (const char* e = std::getenv("GRX_PR_PULL_WALK"))
+          enactor.walk_sorted_list = std::atoi(e) != 0;
         ms = enactor.enact();
         iterations = enactor.iteration;
       } else {

@@ -1042,6 +1042,7 @@ struct pr_pull_enactor_t : gunrock::enactor_t<problem_type> {
   using edge_t = typename problem_type::edge_t;
   using weight_t = typename problem_type::weight_t;
   int max_iterations = 0;
+  bool walk_sorted_list = true;  ///< GRX_PR_PULL_WALK=0: always the per-destination lists
 
   pr_pull_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> ctx,
                     enactor_properties_t props)
@@ -1072,6 +1073,23 @@ struct pr_pull_enactor_t : gunrock::enactor_t<problem_type> {
         },
         weight_t(0), rocprim::plus<weight_t>(), *ctx);
     const weight_t base = (1 - alpha + dangling) / (weight_t)n;
+    // the sums per destination as a walk over the engine's destination-sorted edge list
+    // (operators/by_destination.hxx) once it exists for this graph: one lane per edge, ONE lookup
+    // give[src] per edge, the adds of neighbouring lanes into one rank word combined -- the lists
+    // below keep 16 lanes on a destination and gather at a third of the rate
+    if (walk_sorted_list) {
+      namespace bd = operators::advance::by_destination;
+      if (const void* items = bd::prepared(G, this->unique_id, *ctx)) {
+        hip::for_each_index(n, [rank, base] __device__(std::size_t i) { rank[i] = base; }, ctx->stream());
+        auto gather = [rank, give] __host__ __device__(vertex_t const& src, vertex_t const& dst,
+                                                       edge_t const& edge, weight_t const& w) -> bool {
+          math::atomic::add(rank + dst, give[src] * w);
+          return false;
+        };
+        bd::enqueue(G, items, gather, *ctx);
+        return;
+      }
+    }
     auto in = G.in_edges();
     const unsigned grid = (unsigned)ctx->compute_units() * 8;
     k::row_group_sum_kernel<<<grid, k::RED_BLOCK, 0, ctx->stream()>>>(in, give, base, rank);

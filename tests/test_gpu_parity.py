@@ -194,6 +194,14 @@ def test_pagerank_push_walked_by_destination(ea, oracle, monkeypatch, lb):
                 assert np.abs(p - want).max() < 5e-6, (scale, lb, mode, again, np.abs(p - want).max())
                 assert abs(st.iterations - it) <= 1
             results[mode] = p
+            # the pull form walks the same sorted list from its second iteration on (one lookup per
+            # edge); with the walk switched off it is the per-destination lists of round 2
+            if not sym:
+                G.build_in_edges(c)
+            for again in range(2):
+                q, sq = ea.pagerank(c, G, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
+                assert sq.pull_iterations == sq.iterations
+                assert np.abs(host(q) - want).max() < 5e-6, (scale, mode, again)
             G.close()
             c.close()
         a, b = results.values()

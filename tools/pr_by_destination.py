@@ -24,7 +24,10 @@ for r in range(4):
           f"{st.elapsed_ms / st.iterations:.2f} ms/iteration (wall {wall:.1f} ms), sum {float(p.double().sum()):.6f}",
           flush=True)
 g.build_in_edges(ctx)
-q, sq = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
-q, sq = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
-print(f"pull: {sq.elapsed_ms / sq.iterations:.2f} ms/iteration, {sq.iterations} iterations; "
-      f"max |push - pull| = {float((p - q).abs().max()):.3e}")
+for walk in ("1", "0"):
+    os.environ["GRX_PR_PULL_WALK"] = walk
+    for r in range(3):
+        q, sq = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
+        print(f"pull ({'sorted-list walk' if walk == '1' else 'per-destination lists'}) run {r}: "
+              f"{sq.elapsed_ms / sq.iterations:.2f} ms/iteration, {sq.iterations} iterations; "
+              f"max |push - pull| = {float((p - q).abs().max()):.3e}", flush=True)
