@@ -83,12 +83,27 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+/// the list is read once per walk and is far larger than any cache: a streaming (non-temporal)
+/// load keeps it from evicting what the functor gathers from
+template <bool streaming, typename item_type>
+__device__ __forceinline__ item_type load_item(const item_type* p) {
+  if constexpr (streaming && sizeof(item_type) == 16) {
+    using words_t = unsigned __attribute__((ext_vector_type(4)));
+    const words_t raw = __builtin_nontemporal_load(reinterpret_cast<const words_t*>(p));
+    item_type it;
+    __builtin_memcpy(&it, &raw, sizeof it);
+    return it;
+  } else {
+    return *p;
+  }
+}
+
 /// one edge per lane, neighbouring lanes neighbouring positions of the destination-sorted list
-template <typename item_type, typename operator_t>
+template <bool streaming, typename item_type, typename operator_t>
 __global__ void __launch_bounds__(BLOCK)
     expand_kernel(const item_type* __restrict__ items, long long n, operator_t op) {
   for (long long j = blockIdx.x * (long long)BLOCK + threadIdx.x; j < n; j += (long long)gridDim.x * BLOCK) {
-    const item_type it = items[j];
+    const item_type it = load_item<streaming>(items + j);
     op(it.source, it.destination, it.edge, it.weight);
   }
 }
@@ -219,8 +234,14 @@ void enqueue(graph_t& G, const void* items, operator_t op, gcuda::standard_conte
   const long long nnz = (long long)G.get_number_of_edges();
   const long long blocks = (nnz + k::BLOCK - 1) / k::BLOCK;
   const long long resident = (long long)context.compute_units() * 32;
-  k::expand_kernel<<<(unsigned)(blocks < resident ? blocks : resident), k::BLOCK, 0, context.stream()>>>(
-      reinterpret_cast<const item_type*>(items), nnz, op);
+  const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
+  const char* e = std::getenv("GRX_BY_DESTINATION_STREAM");
+  if (e && std::atoi(e) == 0)
+    k::expand_kernel<false><<<grid, k::BLOCK, 0, context.stream()>>>(
+        reinterpret_cast<const item_type*>(items), nnz, op);
+  else
+    k::expand_kernel<true><<<grid, k::BLOCK, 0, context.stream()>>>(
+        reinterpret_cast<const item_type*>(items), nnz, op);
   GRX_HIP_CHECK(hipGetLastError());
 }
 

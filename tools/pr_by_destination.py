@@ -23,10 +23,16 @@ for r in range(4):
     print(f"run {r}: enact {st.elapsed_ms:.2f} ms, {st.iterations} iterations = "
           f"{st.elapsed_ms / st.iterations:.2f} ms/iteration (wall {wall:.1f} ms), sum {float(p.double().sum()):.6f}",
           flush=True)
+for stream in ("0", "1", "0", "1"):
+    os.environ["GRX_BY_DESTINATION_STREAM"] = stream
+    p, st = ea.pagerank(ctx, g, 0.85, 1e-6)
+    print(f"push, list loaded {'streaming' if stream == '1' else 'plain'}: "
+          f"{st.elapsed_ms / st.iterations:.2f} ms/iteration", flush=True)
 g.build_in_edges(ctx)
 for walk in ("1", "0"):
     os.environ["GRX_PR_PULL_WALK"] = walk
     for r in range(3):
+        os.environ["GRX_BY_DESTINATION_STREAM"] = "01"[r % 2]
         q, sq = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
         print(f"pull ({'sorted-list walk' if walk == '1' else 'per-destination lists'}) run {r}: "
               f"{sq.elapsed_ms / sq.iterations:.2f} ms/iteration, {sq.iterations} iterations; "
