@@ -156,19 +156,37 @@ bool build(graph_t& G, gcuda::workspace_t::by_destination_t& cache, gcuda::stand
     return false;
   hipStream_t s = context.stream();
   const unsigned grid = (unsigned)context.compute_units() * 8u;
+  // gigabytes used once: straight back to the device afterwards, not parked for reuse
+  hip::buffer_t<edge_t> ids, sorted_edges;
+  hip::buffer_t<vertex_t> sorted_columns, rows;
+  hip::buffer_t<unsigned char> temp;
+  for (auto* b : {&ids, &sorted_edges})
+    b->set_parking(false);
+  for (auto* b : {&sorted_columns, &rows})
+    b->set_parking(false);
+  temp.set_parking(false);
   cache.items.set_parking(false);
-  cache.items.reserve(nnz * sizeof(item_type));
-  hip::buffer_t<edge_t> ids(nnz), sorted_edges(nnz);
-  hip::buffer_t<vertex_t> sorted_columns(nnz), rows(nnz);
-  hip::for_each_index_on(nnz, ids.data(), s);
+  std::size_t bytes = 0;
   unsigned bits = 1;
   while (bits < 8 * sizeof(vertex_t) && (n >> bits))
     ++bits;
-  std::size_t bytes = 0;
-  GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, G.get_column_indices(), sorted_columns.data(),
-                                          ids.data(), sorted_edges.data(), nnz, 0, bits, s));
+  try {
+    cache.items.reserve(nnz * sizeof(item_type));
+    ids.reserve(nnz);
+    sorted_edges.reserve(nnz);
+    sorted_columns.reserve(nnz);
+    rows.reserve(nnz);
+    GRX_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, G.get_column_indices(), sorted_columns.data(),
+                                            ids.data(), sorted_edges.data(), nnz, 0, bits, s));
+    temp.reserve(bytes < 256 ? 256 : bytes);  // never null: that would be a size query
+  } catch (const error::exception_t&) {
+    // no room after all (memory held elsewhere in the process): walk row by row, as without the list
+    (void)hipGetLastError();
+    cache.items.release();
+    return false;
+  }
+  hip::for_each_index_on(nnz, ids.data(), s);
   {
-    hip::buffer_t<unsigned char> temp(bytes < 256 ? 256 : bytes);  // never null: that is a size query
     GRX_HIP_CHECK(rocprim::radix_sort_pairs(temp.data(), bytes, G.get_column_indices(),
                                             sorted_columns.data(), ids.data(), sorted_edges.data(), nnz, 0,
                                             bits, s));
@@ -201,8 +219,8 @@ const void* prepared(graph_t& G, unsigned long long run_id, gcuda::standard_cont
                           cache.indices == (const void*)G.get_column_indices() &&
                           cache.values == (const void*)G.get_nonzero_values() &&
                           cache.vertices == (std::size_t)G.get_number_of_vertices() && cache.edges == nnz;
-  if (same_place && cache.built && run_id && cache.checked_for == run_id)
-    return cache.items.data();  // the same enactor compared the contents already
+  if (same_place && run_id && cache.checked_for == run_id && (cache.built || cache.refused))
+    return cache.built ? cache.items.data() : nullptr;  // the same enactor compared the contents already
   const unsigned long long h = detail::fingerprint(G, context);
   if (!same_place || cache.fingerprint != h) {
     cache.offsets = G.get_row_offsets();
@@ -213,13 +231,17 @@ const void* prepared(graph_t& G, unsigned long long run_id, gcuda::standard_cont
     cache.fingerprint = h;
     cache.calls = 0;
     cache.built = false;
+    cache.refused = false;
+    cache.items.release();  // the other graph's list
   }
   cache.checked_for = run_id;
+  if (cache.refused)
+    return nullptr;
   if (!cache.built) {
     if (++cache.calls < 2)
       return nullptr;  // a graph walked once is not worth a sort
     if (!detail::build(G, cache, context)) {
-      cache.calls = 0;
+      cache.refused = true;
       return nullptr;
     }
     cache.built = true;

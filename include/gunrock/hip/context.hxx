@@ -163,6 +163,7 @@ class workspace_t {
     unsigned long long current_run = 0;  ///< enactor whose advance is being dispatched (0: none)
     unsigned calls = 0;                  ///< whole-graph advances without an output seen on this graph
     bool built = false;
+    bool refused = false;                ///< device memory did not allow the list: not tried again for this graph
     hip::buffer_t<unsigned char> items;  ///< [edges] {source, destination, edge, weight}
   };
   by_destination_t& by_destination() { return by_destination_; }
