@@ -547,17 +547,27 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   const int lane = lane_id();
   if (blockIdx.x == 0 && tid < 8)  // the expansion kernel's claim cursors start from zero
     claim_cursors[tid * CLAIM_LINE] = 0ull;
-  // a workgroup takes 2048 CONSECUTIVE slots at a time, eight per thread (eight independent row
-  // lookups in flight per lane), and reserves queue space for all their hubs with ONE atomic
-  const std::size_t n_super = (n_in + CLASSIFY_TILE - 1) / CLASSIFY_TILE;
-  for (std::size_t st = blockIdx.x; st < n_super; st += gridDim.x) {
+  // a workgroup takes 2048 slots at a time, eight per thread (eight independent row lookups in
+  // flight per lane), and reserves queue space for all their hubs with ONE atomic.  The slots of
+  // a wavefront are 64 consecutive ones (one mask word, coalesced loads); consecutive GROUPS of 64
+  // go to different workgroups: an ascending frontier of the hot-first copy starts with all its
+  // hubs, and 2048 consecutive slots would leave their descriptors to one workgroup (42 us of
+  // SSSP's second wide iteration against 8 us for as many slots without hubs)
+  const std::size_t n_groups = (n_in + wave_size - 1) / wave_size;
+  const std::size_t groups_per_step = (std::size_t)gridDim.x * (CLASSIFY_TILE / wave_size);
+  const std::size_t wave_in_block = (std::size_t)(tid / wave_size);
+  for (std::size_t step = 0; step < n_groups; step += groups_per_step) {
     vertex_t v[CLASSIFY_SLOTS];
     edge_t first[CLASSIFY_SLOTS];
     unsigned deg[CLASSIFY_SLOTS];
     unsigned mine = 0;
+    auto slot_of = [&](int k) -> std::size_t {
+      return (step + ((std::size_t)k * ADV_WAVES + wave_in_block) * gridDim.x + blockIdx.x) * wave_size +
+             (std::size_t)lane;
+    };
 #pragma unroll
     for (int k = 0; k < CLASSIFY_SLOTS; ++k) {
-      const std::size_t idx = st * CLASSIFY_TILE + (std::size_t)k * ADV_BLOCK + tid;
+      const std::size_t idx = slot_of(k);
       v[k] = gunrock::numeric_limits<vertex_t>::invalid();
       if (idx < n_in)
         v[k] = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
@@ -583,18 +593,42 @@ __global__ void __launch_bounds__(ADV_BLOCK)
     unsigned long long at = total ? s_base + excl : 0ull;
 #pragma unroll
     for (int k = 0; k < CLASSIFY_SLOTS; ++k) {
-      const std::size_t idx = st * CLASSIFY_TILE + (std::size_t)k * ADV_BLOCK + tid;
+      const std::size_t idx = slot_of(k);
       const unsigned my_chunks = (deg[k] >= hub_threshold) ? (deg[k] + chunk_edges - 1) / chunk_edges : 0u;
       // a list is queued only when ALL its chunks fit; one that does not stays in its tile (slow,
       // correct) and the slots it reserved below the capacity become empty chunks
       const bool queued = my_chunks && at + my_chunks <= chunk_capacity;
-      for (unsigned c = 0; c < my_chunks && at + c < chunk_capacity; ++c) {
-        const unsigned off = c * chunk_edges;
-        chunk_t<vertex_t, edge_t> d;
-        d.source = v[k];
-        d.first = first[k] + (edge_t)off;
-        d.count = queued ? (int)((deg[k] - off < chunk_edges) ? deg[k] - off : chunk_edges) : 0;
-        chunks[at + c] = d;
+      // a list of a few chunks is written by its lane; a longer one by the whole wavefront, chunk
+      // c by lane c % 64 (the 320 K edges of R-MAT-22's largest hub are 313 descriptors: written by
+      // one lane they were 40 of the 46-61 us this pass took on the level that holds the hubs)
+      constexpr unsigned LANE_CHUNKS = 4;
+      if (my_chunks <= LANE_CHUNKS)
+        for (unsigned c = 0; c < my_chunks && at + c < chunk_capacity; ++c) {
+          const unsigned off = c * chunk_edges;
+          chunk_t<vertex_t, edge_t> d;
+          d.source = v[k];
+          d.first = first[k] + (edge_t)off;
+          d.count = queued ? (int)((deg[k] - off < chunk_edges) ? deg[k] - off : chunk_edges) : 0;
+          chunks[at + c] = d;
+        }
+      for (unsigned long long longs = __ballot(my_chunks > LANE_CHUNKS); longs; longs &= longs - 1) {
+        const int owner = __ffsll((long long)longs) - 1;
+        const vertex_t hub = __shfl(v[k], owner);
+        const edge_t hub_first = __shfl(first[k], owner);
+        const unsigned hub_degree = __shfl(deg[k], owner);
+        const unsigned hub_chunks = __shfl(my_chunks, owner);
+        const bool hub_queued = __shfl((int)queued, owner) != 0;
+        const unsigned long long hub_at =
+            ((unsigned long long)(unsigned)__shfl((int)(unsigned)(at >> 32), owner) << 32) |
+            (unsigned)__shfl((int)(unsigned)at, owner);
+        for (unsigned c = (unsigned)lane; c < hub_chunks && hub_at + c < chunk_capacity; c += wave_size) {
+          const unsigned off = c * chunk_edges;
+          chunk_t<vertex_t, edge_t> d;
+          d.source = hub;
+          d.first = hub_first + (edge_t)off;
+          d.count = hub_queued ? (int)((hub_degree - off < chunk_edges) ? hub_degree - off : chunk_edges) : 0;
+          chunks[hub_at + c] = d;
+        }
       }
       at += my_chunks;
       // 64 consecutive, 64-aligned slots per wavefront and k: one mask word
