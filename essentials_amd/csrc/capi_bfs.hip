@@ -34,6 +34,7 @@ extern "C" int grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t source, int32_t
                            ctx->mc);
       if (run_on != g)
         problem.scatter_to = g->hot_vertex_of.data();
+        problem.gather_from = g->hot_rank_of_device.data();
       // push search: one byte per vertex while it runs once 4-byte depths outgrow the eight L2s
       // (GRX_BFS_BYTE_LABELS=0/1 overrides; measurements in DESIGN.md, "Larger graphs")
       if (!o.direction_optimized) {

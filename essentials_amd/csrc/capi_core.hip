@@ -137,6 +137,7 @@ grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
   GRX_HIP_CHECK(hipMemcpy(g->hot_rank_of.data(), R.rank_of.data(), (std::size_t)g->n_rows * 4,
                           hipMemcpyDeviceToHost));
   g->hot_vertex_of = std::move(R.vertex_of);
+  g->hot_rank_of_device = std::move(R.rank_of);
   g->hot = std::move(h);
   return g->hot.get();
 }
@@ -152,6 +153,7 @@ int grx_graph_hot_first(grx_context_t ctx, grx_graph_t g, int enable) {
       g->hot_first = 0;
       g->hot.reset();
       g->hot_vertex_of = hip::device_array_t<int32_t>();
+      g->hot_rank_of_device = hip::device_array_t<int32_t>();
       g->hot_rank_of.clear();
       g->hot_rank_of.shrink_to_fit();
       return (int)GRX_OK;

@@ -123,6 +123,7 @@ struct grx_graph_s {
   std::unique_ptr<grx_graph_s> hot;
   gunrock::hip::device_array_t<int32_t> hot_vertex_of;  // device: caller's id of a renumbered vertex
   std::vector<int32_t> hot_rank_of;                     // host: renumbered id of a caller's vertex
+  gunrock::hip::device_array_t<int32_t> hot_rank_of_device;  // the same on the device (label delivery)
   // this handle IS a slice of a renumbered copy (grx_graph_partition_hot_first): the two arrays
   // above are the permutations grx_partitioned_run translates with
   bool renumbered_slice = false;

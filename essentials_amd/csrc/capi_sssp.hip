@@ -40,6 +40,7 @@ extern "C" int grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t source, float*
                            ctx->mc);
       if (run_on != g)
         problem.scatter_to = g->hot_vertex_of.data();
+        problem.gather_from = g->hot_rank_of_device.data();
       // one 64-bit label per vertex (one RMW per improvement) while 8 bytes per vertex stay
       // cache-sized; beyond that the doubled label footprint costs more lookups that miss than the
       // saved RMWs are worth.  Measured crossover on R-MAT (tools/sssp_packed_vs_words.py, mean
