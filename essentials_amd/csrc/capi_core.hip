@@ -93,9 +93,9 @@ int essentials_amd::ensure_can_pull(grx_context_s* ctx, grx_graph_s* g) {
   return GRX_OK;
 }
 
-grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
+grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g, bool csr_only) {
   std::lock_guard<std::mutex> lock(g->hot_mutex);
-  if (g->in_edges)
+  if (g->in_edges && !csr_only)
     return nullptr;  // attached after the copy was made: the copy has no transpose
   if (g->hot) {
     g->hot->symmetry = g->symmetry;  // may have been verified since
@@ -106,9 +106,9 @@ grx_graph_s* essentials_amd::hot_copy(grx_context_s* ctx, grx_graph_s* g) {
     // automatic: graphs whose labels outgrow a CU's LDS image and whose traversal is worth the
     // second copy of the CSR; a graph with attached in-edges (directed) keeps its numbering -- the
     // transpose would have to be renumbered too
-    want = g->n_rows == g->n_cols && g->n_rows >= (1 << 16) && g->nnz >= (1 << 20) && !g->in_edges;
+    want = g->n_rows == g->n_cols && g->n_rows >= (1 << 16) && g->nnz >= (1 << 20) && (!g->in_edges || csr_only);
     if (const char* e = std::getenv("GRX_HOT_FIRST"))
-      want = std::atoi(e) != 0 && g->n_rows == g->n_cols && !g->in_edges;
+      want = std::atoi(e) != 0 && g->n_rows == g->n_cols && (!g->in_edges || csr_only);
   }
   if (!want || g->n_rows < 2)
     return nullptr;

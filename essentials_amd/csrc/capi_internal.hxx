@@ -85,7 +85,9 @@ int ensure_can_pull(grx_context_s* ctx, grx_graph_s* g);
 /// The hot-first renumbered copy of `g` (graph::build::hot_first) the traversals run on, built on
 /// first use; nullptr when the handle or GRX_HOT_FIRST says no, or the graph is too small for it
 /// to matter (capi_core.hip).  Call inside guarded().
-grx_graph_s* hot_copy(grx_context_s* ctx, grx_graph_s* g);
+/// `csr_only`: the caller walks out-edges only (PageRank), so a graph with an attached transpose --
+/// whose copy would have none -- may run on its copy too.
+grx_graph_s* hot_copy(grx_context_s* ctx, grx_graph_s* g, bool csr_only = false);
 }  // namespace essentials_amd
 
 struct grx_graph_s {

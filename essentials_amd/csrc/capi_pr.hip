@@ -23,8 +23,26 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
         if (int rc = ensure_can_pull(ctx, g))
           return rc;
       scoped_options scope(ctx->single(), &o);
-      graph_type G = g->view();
+      // both forms run on the hot-first renumbered copy of the graph (reorder.hxx) when it is large
+      // enough for the walk over the destination-sorted edge list (operators/by_destination.hxx:
+      // that walk needs out-edges only) and hand the ranks over in the caller's numbering
+      grx_graph_s* run_on = g;
+      const unsigned long long walk_from = ctx->single().options().by_destination_min_edges;
+      if (walk_from && (unsigned long long)g->nnz >= walk_from)
+        if (grx_graph_s* h = hot_copy(ctx, g, /*csr_only=*/true))
+          run_on = h;
+      if (const char* e = std::getenv("GRX_PR_HOT_FIRST"))
+        if (std::atoi(e) == 0)
+          run_on = g;
+      bool pull_walk = true;  // GRX_PR_PULL_WALK=0: round 2's per-destination lists (they need the transpose)
+      if (const char* e = std::getenv("GRX_PR_PULL_WALK"))
+        pull_walk = std::atoi(e) != 0;
+      if (o.direction_optimized && !pull_walk)
+        run_on = g;
+      graph_type G = run_on->view();
       problem_type problem(G, alpha, tol, d_p, ctx->mc);
+      if (run_on != g)
+        problem.gather_from = g->hot_rank_of_device.data();
       problem.pull = o.direction_optimized != 0;
       problem.init();
       problem.reset();
@@ -35,8 +53,7 @@ extern "C" int grx_pagerank(grx_context_t ctx, grx_graph_t g, float alpha, float
       if (problem.pull) {
         clients::pr_pull_enactor_t<problem_type> enactor(&problem, ctx->mc, props);
         enactor.max_iterations = o.max_iterations;
-        if (const char* e = std::getenv("GRX_PR_PULL_WALK"))
-          enactor.walk_sorted_list = std::atoi(e) != 0;
+        enactor.walk_sorted_list = pull_walk;
         ms = enactor.enact();
         iterations = enactor.iteration;
       } else {
