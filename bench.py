@@ -160,9 +160,21 @@ def pagerank_leg(ea, ctx, a) -> dict:
         _, st = ea.pagerank(ctx, g, 0.85, 1e-6)
         out["push"] = leg(st)
         out["push"]["first_run"] = first
+        out["push"]["note"] = ("pr.hxx's lambda (two lookups by source per edge) through grx_pagerank: on the "
+                               "hot-first copy of the graph, ranks handed over in the caller's numbering")
         g.build_in_edges(ctx)
         _, st = ea.pagerank(ctx, g, 0.85, 1e-6, options=ea.Options(direction_optimized=True))
         out["pull"] = leg(st)
+        out["pull"]["note"] = ("own client: one pre-multiplied lookup per edge over the same destination-sorted "
+                               "list of the hot-first copy")
+        # the same on the caller's numbering: what the unchanged pr.hxx gets from the engine
+        os.environ["GRX_PR_HOT_FIRST"] = "0"
+        try:
+            ea.pagerank(ctx, g, 0.85, 1e-6)            # this numbering's sorted list is built here
+            _, st = ea.pagerank(ctx, g, 0.85, 1e-6)
+            out["push_callers_numbering"] = leg(st)
+        finally:
+            del os.environ["GRX_PR_HOT_FIRST"]
         g.close()
         return out
     except Exception as e:   # never lose the headline line to the side leg
@@ -220,7 +232,7 @@ def attach_pmc(out: dict, a, world: int) -> None:
         out["roofline"]["l2_hit_rate"] = l2.get("hit_rate_bfs_advance")
     pr = out.get("pagerank")
     if isinstance(pr, dict):
-        for form in ("push", "pull"):
+        for form in ("push", "pull", "push_callers_numbering"):
             rec = pmc.get("traffic", {}).get("pagerank_" + form)
             if rec and form in pr and "roofline" in pr[form]:
                 pr[form]["roofline"]["traffic"] = rec["bytes_per_iteration"]

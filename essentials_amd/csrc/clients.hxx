@@ -15,6 +15,7 @@
  * pr.hxx:64-178.  Independently written; the schedule is a template parameter.
  */
 #pragma once
+#include <numeric>
 
 #include <gunrock/hip/kernels/reduce_kernels.hxx>
 
@@ -921,18 +922,27 @@ struct sssp_enactor_t : gunrock::enactor_t<problem_type> {
 // ---------------------------------------------------------------------------
 template <typename graph_t, typename weight_t>
 __global__ void __launch_bounds__(256)
-    out_scale_kernel(graph_t G, std::size_t n, weight_t alpha, weight_t* scale) {
+    out_scale_kernel(graph_t G, std::size_t n, unsigned long long stride, weight_t alpha, weight_t* scale) {
   using vertex_t = typename graph_t::vertex_type;
   using edge_t = typename graph_t::edge_type;
   const unsigned lane = threadIdx.x & 63u;
   const std::size_t waves = (std::size_t)gridDim.x * 4;
-  for (std::size_t v = (std::size_t)blockIdx.x * 4 + threadIdx.x / 64; v < n; v += waves) {
+  // wavefront w takes rows (i * stride) mod n for i = w, w + waves, ...: with i itself, the rows of
+  // one wavefront are a power-of-two apart, which in an R-MAT numbering are all the hubs (20 ms of
+  // one wavefront walking them one after the other, against 2 ms)
+  for (std::size_t i = (std::size_t)blockIdx.x * 4 + threadIdx.x / 64; i < n; i += waves) {
+    const std::size_t v = (std::size_t)(((unsigned long long)i * stride) % (unsigned long long)n);
     const edge_t begin = G.get_starting_edge((vertex_t)v);
     const edge_t count = G.get_number_of_neighbors((vertex_t)v);
-    weight_t total = 0;
-    for (edge_t e = (edge_t)lane; e < count; e += 64)
+    weight_t total = 0, more = 0;
+    edge_t e = (edge_t)lane;
+    for (; e + 64 < count; e += 128) {  // two loads in flight
       total += G.get_edge_weight(begin + e);
-    total = hip::wave_sum(total);
+      more += G.get_edge_weight(begin + e + 64);
+    }
+    if (e < count)
+      total += G.get_edge_weight(begin + e);
+    total = hip::wave_sum(total + more);
     if (lane == 0)
       scale[v] = total != 0 ? alpha / total : weight_t(0);
   }
@@ -1019,7 +1029,13 @@ struct pr_problem_t : gunrock::problem_t<graph_t> {
     hip::fill(previous.data(), n, weight_t(0), ctx->stream());
     // alpha / (sum of a vertex's out-weights): one WAVEFRONT per row (a thread per row walked the
     // 370 K edges of R-MAT-24's largest hub alone: 52 ms of every reset against 1.6 ms)
-    out_scale_kernel<<<(unsigned)ctx->compute_units() * 8u, 256, 0, ctx->stream()>>>(g, n, alpha,
+    unsigned long long stride = 1;  // coprime with n: i -> (i * stride) mod n is a permutation
+    for (unsigned long long p : {2654435761ull, 40503ull, 7919ull, 104729ull, 1299709ull})
+      if (n > 1 && std::gcd(p % (unsigned long long)n, (unsigned long long)n) == 1 && p % n != 0) {
+        stride = p % (unsigned long long)n;
+        break;
+      }
+    out_scale_kernel<<<(unsigned)ctx->compute_units() * 8u, 256, 0, ctx->stream()>>>(g, n, stride, alpha,
                                                                                        out_scale.data());
     GRX_HIP_CHECK(hipGetLastError());
     ctx->synchronize();

@@ -75,7 +75,8 @@ def attribute_all(names):
                     break
     # one run = from a problem's reset pass (index_kernel over `...problem_t<...>::reset()`'s lambda)
     # to the next one; round 2 cut at reach_stats_kernel, which the default forms no longer launch
-    starts = [i for i, n in enumerate(names) if "problem_t<" in n and "::reset()" in n]
+    starts = [i for i, n in enumerate(names)
+              if ("problem_t<" in n and "::reset()" in n) or "out_scale_kernel" in n]  # PageRank's reset pass
     for a, b in zip(starts, starts[1:] + [len(out)]):
         run = range(a, b)
         mine = [out[j][0] for j in run if out[j][1] == "bfs"]
@@ -93,6 +94,17 @@ def attribute_all(names):
             for j in run:
                 if out[j][1] == "pagerank_push":
                     out[j] = (out[j][0], "pagerank_push_first_run")
+    # bench.py's push runs AFTER its pull leg are on the caller's numbering (GRX_PR_HOT_FIRST=0: what
+    # the unchanged pr.hxx gets); the ones before it on the hot-first copy
+    seen_pull = False
+    for a, b in zip(starts, starts[1:] + [len(out)]):
+        clients = {out[j][1] for j in range(a, b)}
+        if "pagerank_pull" in clients:
+            seen_pull = True
+        elif seen_pull:
+            for j in range(a, b):
+                if out[j][1].startswith("pagerank_push"):
+                    out[j] = (out[j][0], out[j][1].replace("pagerank_push", "pagerank_push_callers_numbering"))
     return out
 
 
@@ -215,6 +227,9 @@ tr = {"bfs": traffic("bfs", pmc_runs.get("bfs"), ADVANCE),
       "sssp": traffic("sssp", pmc_runs.get("sssp"), ADVANCE),
       "sssp_two_pass": traffic("sssp_two_pass", pmc_runs.get("sssp_two_pass"), ADVANCE),
       "pagerank_push": traffic("pagerank_push", pmc_pr.get("push", {}).get("iterations"), None, "iteration"),
+      "pagerank_push_callers_numbering": traffic("pagerank_push_callers_numbering",
+                                                 pmc_pr.get("push_callers_numbering", {}).get("iterations"), None,
+                                                 "iteration"),
       "pagerank_pull": traffic("pagerank_pull", pmc_pr.get("pull", {}).get("iterations"), None, "iteration")}
 # calibration on the gather probe: bench.py calls grx_measure_gather_rate twice (agent-scope and plain
 # loads), each 1 warm-up + 5 timed passes over the E column indices
