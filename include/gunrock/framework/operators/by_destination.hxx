@@ -221,8 +221,15 @@ const void* prepared(graph_t& G, unsigned long long run_id, gcuda::standard_cont
                           cache.vertices == (std::size_t)G.get_number_of_vertices() && cache.edges == nnz;
   if (same_place && run_id && cache.checked_for == run_id && (cache.built || cache.refused))
     return cache.built ? cache.items.data() : nullptr;  // the same enactor compared the contents already
+  // an enactor that advances over several graphs in turn would drop and fingerprint a list per call
+  if (run_id && cache.alternating_in == run_id && cache.switches >= 3)
+    return nullptr;
   const unsigned long long h = detail::fingerprint(G, context);
   if (!same_place || cache.fingerprint != h) {
+    if (run_id && cache.checked_for == run_id) {  // this enactor was on another graph a call ago
+      cache.switches = cache.alternating_in == run_id ? cache.switches + 1 : 1;
+      cache.alternating_in = run_id;
+    }
     cache.offsets = G.get_row_offsets();
     cache.indices = G.get_column_indices();
     cache.values = G.get_nonzero_values();

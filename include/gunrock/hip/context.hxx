@@ -164,6 +164,8 @@ class workspace_t {
     unsigned calls = 0;                  ///< whole-graph advances without an output seen on this graph
     bool built = false;
     bool refused = false;                ///< device memory did not allow the list: not tried again for this graph
+    unsigned long long alternating_in = 0;  ///< enactor that keeps switching graphs (0: none) ...
+    unsigned switches = 0;                  ///< ... and how often it did: no list for that enactor
     hip::buffer_t<unsigned char> items;  ///< [edges] {source, destination, edge, weight}
   };
   by_destination_t& by_destination() { return by_destination_; }
