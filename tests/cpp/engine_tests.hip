@@ -629,6 +629,41 @@ int main(int argc, char** argv) {
       std::vector<long long> as_int(want.begin(), want.end());
       dump_array("by_destination_sums_reweighted", as_int);
     }
+    // one enactor advancing over two graphs in turn: right sums from either, and after three
+    // switches the operator stops sorting (and fingerprinting) lists for that enactor
+    {
+      auto d_ax2 = upload(ax2);
+      auto G2 = graph::build::from_csr<memory_space_t::device, graph::view_t::csr>(
+          hg.n, hg.n, (int)hg.aj.size(), d_ap.data(), d_aj.data(), d_ax2.data());
+      std::vector<float> want1(hg.n, 0.0f);
+      for (int v = 0; v < hg.n; ++v)
+        for (int e = hg.ap[v]; e < hg.ap[v + 1]; ++e) want1[hg.aj[e]] += hg.ax[e] * (float)(1 + v % 3);
+      auto spread2 = [G2, ps, pc, pw] __host__ __device__(vertex_t const& s, vertex_t const& d, edge_t const& e,
+                                                           weight_t const& w) -> bool {
+        if (G2.get_destination_vertex(e) != d || G2.get_edge_weight(e) != w)
+          math::atomic::add(pw, 1);
+        math::atomic::add(pc + e, 1);
+        math::atomic::add(ps + d, w * (float)(1 + s % 3));
+        return false;
+      };
+      problem_type P(G, mc);
+      toy_enactor_t<problem_type> E(&P, mc);
+      for (int call = 0; call < 10; ++call) {
+        sums.zero(); calls.zero(); wrong.zero();
+        if (call % 2 == 0)
+          operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::graph,
+                                      operators::advance_io_type_t::none>(G, &E, spread, *mc);
+        else
+          operators::advance::execute<lbt::block_mapped, operators::advance_direction_t::forward,
+                                      operators::advance_io_type_t::graph,
+                                      operators::advance_io_type_t::none>(G2, &E, spread2, *mc);
+        CHECK(wrong.to_host()[0] == 0);
+        CHECK(sums.to_host() == (call % 2 == 0 ? want1 : want));
+        CHECK(!cache.built);  // never two calls in a row on one graph
+      }
+      CHECK(cache.switches >= 3 && cache.alternating_in == E.unique_id);
+    }
     // math::atomic::add on floats combines runs of neighbouring lanes with the same address: the
     // totals are those of one add per lane, and the values returned for one word are the word's
     // values in ONE order of the adds (all ones added: 0, 1, 2, ... each exactly once)
