@@ -259,8 +259,9 @@ struct bfs_enactor_t : gunrock::enactor_t<problem_type> {
         unsigned long long* bit_words = nullptr;
         if ((std::size_t)G.get_number_of_vertices() >= operators::advance::settled_max_ids)
           bit_words = settled.prepare((std::size_t)G.get_number_of_vertices(), bit_limit);
-        operators::filter::select_range(G, n_scan, found_now, *E->get_output_frontier(), *ctx,
-                                        hip::kernels::select_no_each_t(), has_depth, bit_words, bit_limit);
+        operators::filter::select_range</*narrow_claims=*/true>(
+            G, n_scan, found_now, *E->get_output_frontier(), *ctx, hip::kernels::select_no_each_t(), has_depth,
+            bit_words, bit_limit);
         E->swap_frontier_buffers();
         return;
       }

@@ -137,11 +137,11 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output,
  * @brief output <- the vertices v in [0, n) with pred(v), and output's work hint <- the sum of their
  * degrees: what `output.sequence(0, n)` followed by filter::execute<predicated>(G, pred, ...) yields
  * as a SET (reference frontier.hxx sequence + filter/predicated.hxx:24-38), in one pass and with
- * ids ascending inside every run of 8192 candidates (compact_kernels.hxx: select_range_kernel).
+ * ids ascending inside every run of 8192 (4096 with `narrow_claims`) candidates (compact_kernels.hxx: select_range_kernel).
  * The engine extension behind "run a wide level without an output frontier, then name what it found".
  * pred is called exactly once per v, in no particular order.  Synchronous.
  */
-template <typename graph_t, typename pred_t, typename frontier_t,
+template <bool narrow_claims = false, typename graph_t, typename pred_t, typename frontier_t,
           typename each_t = ::gunrock::hip::kernels::select_no_each_t,
           typename bit_t = ::gunrock::hip::kernels::select_no_bit_t>
 void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
@@ -163,10 +163,11 @@ void select_range(graph_t& G, std::size_t n, pred_t pred, frontier_t& output,
   }
   if (output.get_capacity() < n)  // at most every candidate is selected: the pass runs ONCE
     output.reserve(n);
-  const std::size_t chunks = (n_visit + k::SEL_CHUNK - 1) / k::SEL_CHUNK;
+  constexpr int items = narrow_claims ? k::SEL_ITEMS_NARROW : k::SEL_ITEMS_WIDE;
+  const std::size_t chunks = (n_visit + (std::size_t)k::SEL_BLOCK * items - 1) / ((std::size_t)k::SEL_BLOCK * items);
   const std::size_t cap = (std::size_t)context.compute_units() * 2;
   operators::advance::detail::clocked_t clock(context);  // it IS a level's output path: timed with the advances
-  k::select_range_kernel<vertex_t><<<(unsigned)(chunks < cap ? chunks : cap), k::SEL_BLOCK, 0,
+  k::select_range_kernel<vertex_t, items><<<(unsigned)(chunks < cap ? chunks : cap), k::SEL_BLOCK, 0,
                                      context.stream()>>>(G, n_visit, pred, output.data(), output.get_capacity(),
                                                          context.workspace().counters(), (int)k::C_OUT,
                                                          (int)k::C_NEXT_WORK, (int)k::C_OVERFLOW, n, each, bit,

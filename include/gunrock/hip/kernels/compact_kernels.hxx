@@ -132,8 +132,12 @@ __global__ void __launch_bounds__(CMP_BLOCK)
 // between chunks is the order in which workgroups claimed space.
 // ---------------------------------------------------------------------------
 constexpr int SEL_BLOCK = 1024;
-constexpr int SEL_ITEMS = 8;
-constexpr int SEL_CHUNK = SEL_BLOCK * SEL_ITEMS;  // 8192 ids per claim
+// ids per thread and claim, chosen by the caller: 8 (8192 ids per claim) keeps more loads in flight
+// for predicates with side products (SSSP's scan: 20 / 19 / 16 us against 26 / 25 / 21 with 4); 4
+// gives a plain label scan twice the workgroups (R-MAT-22's 2.4 M ids are 300 claims of 8192, 1.2
+// per CU: 29 / 19 us against 26 / 14)
+constexpr int SEL_ITEMS_WIDE = 8;
+constexpr int SEL_ITEMS_NARROW = 4;
 constexpr int SEL_WAVES = SEL_BLOCK / wave_size;  // 16
 
 /// Side products of the same pass (both optional): `each(i)` runs once for every id (lane-local side
@@ -149,7 +153,7 @@ struct select_no_bit_t {
   __device__ __forceinline__ bool operator()(vertex_t const&) const { return false; }
 };
 
-template <typename vertex_t, typename graph_t, typename pred_t, typename each_t, typename bit_t>
+template <typename vertex_t, int SEL_ITEMS, typename graph_t, typename pred_t, typename each_t, typename bit_t>
 __global__ void __launch_bounds__(SEL_BLOCK)
     select_range_kernel(graph_t G, std::size_t n, pred_t pred, vertex_t* __restrict__ out,
                         std::size_t capacity, unsigned long long* counters, int cursor_slot,
@@ -158,6 +162,7 @@ __global__ void __launch_bounds__(SEL_BLOCK)
   __shared__ unsigned s_count[SEL_ITEMS * SEL_WAVES];   // matches per (k, wave), then their prefix
   __shared__ unsigned long long s_base;
   __shared__ unsigned long long s_work[SEL_WAVES];
+  constexpr int SEL_CHUNK = SEL_BLOCK * SEL_ITEMS;
   const int tid = threadIdx.x, lane = lane_id(), wave = tid / wave_size;
   unsigned long long work = 0;
   const std::size_t n_chunks = (n + SEL_CHUNK - 1) / SEL_CHUNK;
@@ -182,11 +187,19 @@ __global__ void __launch_bounds__(SEL_BLOCK)
         s_count[k * SEL_WAVES + wave] = (unsigned)__popcll(mask[k]);
     }
     __syncthreads();
-    if (wave == 0) {  // exclusive prefix over the 128 (k, wave) groups, two per lane
-      const unsigned a = s_count[2 * lane], b = s_count[2 * lane + 1];
-      const unsigned incl = wave_inclusive_sum(a + b);
-      s_count[2 * lane] = incl - a - b;
-      s_count[2 * lane + 1] = incl - b;
+    if (wave == 0) {  // exclusive prefix over the (k, wave) groups, one or two per lane
+      static_assert(SEL_ITEMS * SEL_WAVES == wave_size || SEL_ITEMS * SEL_WAVES == 2 * wave_size, "group scan");
+      unsigned incl;
+      if constexpr (SEL_ITEMS * SEL_WAVES == 2 * wave_size) {
+        const unsigned a = s_count[2 * lane], b = s_count[2 * lane + 1];
+        incl = wave_inclusive_sum(a + b);
+        s_count[2 * lane] = incl - a - b;
+        s_count[2 * lane + 1] = incl - b;
+      } else {
+        const unsigned a = s_count[lane];
+        incl = wave_inclusive_sum(a);
+        s_count[lane] = incl - a;
+      }
       if (lane == wave_size - 1)
         s_base = incl ? atomicAdd(&counters[cursor_slot], (unsigned long long)incl) : 0ull;
     }
