@@ -395,7 +395,7 @@ void execute(graph_t& G,
       const unsigned fgrid = (unsigned)context.compute_units() * context.options().fused_blocks_per_cu;
       k::expand_fused_kernel<input_type, output_type><<<fgrid, k::ADV_BLOCK, 0, context.stream()>>>(
           G, op, input.data(), n_in, nullptr, out_ptr, capacity, counters, chunks, chunk_capacity, mask,
-          cursors);
+          cursors, input_type == advance_io_type_t::vertices && input.ascending() && detail::dealt_mode() ? 1 : 0);
     }
   } else if (holes) {
     k::block_mapped_kernel<true, dynamic_tiles, input_type, output_type>

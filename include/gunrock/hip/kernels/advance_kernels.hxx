@@ -659,7 +659,8 @@ __global__ void __launch_bounds__(ADV_BLOCK)
                         const chunk_t<vertex_t, edge_t>* __restrict__ chunks,
                         unsigned long long chunk_capacity,
                         const unsigned long long* __restrict__ hub_mask,
-                        unsigned long long* __restrict__ claim_cursors) {
+                        unsigned long long* __restrict__ claim_cursors,
+                        int dealt = 0) {
   using weight_t = typename graph_t::weight_type;
   constexpr bool HAS_OUT = (OUT != advance_io_type_t::none);
   if (n_in_device)
@@ -684,7 +685,15 @@ __global__ void __launch_bounds__(ADV_BLOCK)
   auto fetch_slot = [&](unsigned long long t, vertex_t& v, edge_t& first, edge_t& last) {
     v = gunrock::numeric_limits<vertex_t>::invalid();
     first = last = 0;
-    const std::size_t idx = (std::size_t)t * ADV_BLOCK + tid;
+    // an ASCENDING frontier of the hot-first copy is falling degrees: 256 consecutive slots would
+    // make the first tiles 50 times the work of the last (one workgroup walking 64 K edges while the
+    // others idle: 106 us for SSSP's 77 K-slot iteration).  Dealt, a tile is 16 groups of 16
+    // consecutive slots, group g of tile t being group g * tiles + t of the frontier: the hottest 256
+    // slots go to 16 tiles, and 16 neighbouring ids still share their row-offset lines (single slots
+    // dealt: 47 us there, but 19 -> 41 us on a BFS level of 185 K slots that had no skew to fix)
+    constexpr unsigned DEAL = 16;
+    const std::size_t idx = dealt ? ((std::size_t)(tid / DEAL) * n_tiles + t) * DEAL + tid % DEAL
+                                  : (std::size_t)t * ADV_BLOCK + tid;
     if (t < n_tiles && idx < n_in) {
       const vertex_t x = (IN == advance_io_type_t::graph) ? (vertex_t)idx : input[idx];
       const bool hub = (hub_mask[idx / wave_size] >> (idx % wave_size)) & 1ull;
